@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric:
+"Mpixels/sec end-to-end scale2.0x 7-layer conv, 1/2/4/8 GPU + host-CPU baseline").
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one convertWithModels pass (7 layers: pad-7 by clamped loads, 7 kernel launches,
+crop/stitch in the last kernel's store) over one frame per GPU:
+
+  workload "scale2x_1080p" (BASELINE.json configs[1]): synthetic 1920x1080 RGB frame -> luma
+  Y = 0.299R + 0.587G + 0.114B on /255 floats -> nearest-neighbour 2x (main.cpp:132-140) ->
+  CNN plane 2160x3840 fp32, scale2.0x topology 1-32-32-64-64-128-128-1 with seeded synthetic
+  weights (the shipped JSON models are stripped from the reference; see oracle/gen_model.py).
+
+Input and output planes are resident in HBM when the timed region starts (device-pointer entry
+point w2xc_convert_plane_device); `value` is whole-job input-image Mpix/s = N * 1920*1080 * K / t
+(the CNN runs on 4x as many pixels).  Multi-GPU: one process per GPU, every rank converts its own
+frame (the path shards into independent frames / row bands, no collective on the data path), so
+per-GPU work is fixed: "scaling": "weak".  torch.distributed (RCCL) is used only for the barrier
+and the MAX over ranks of the elapsed time.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = layer 6 (conv3x3_mfma, 128->128, 51% of the FLOPs): algorithmic
+               FLOPs of one launch / its average duration from hipEvents recorded on the launch
+               stream inside the timed region (w2xc_opts.profile), vs the 157.3 TFLOP/s fp32 MFMA peak.
+  cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real
+               binary cannot be built) timed on this host's cores on a bounded sample of whole 512^2
+               blocks of the same plane (the reference's block-split path costs the same per block).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PX = {  # 2*9*cin*cout per CNN pixel
+    (1, 32): 576, (32, 32): 18432, (32, 64): 36864, (64, 64): 73728, (64, 128): 147456, (128, 128): 294912, (128, 1): 2304,
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_frame_luma(seed, h=1080, w=1920):
+    """seeded RGB uint8 frame -> Y plane in [0,1] (OpenCV RGB2YUV luma weights) -> nearest 2x"""
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8).astype(np.float32) / np.float32(255.0)
+    y = (np.float32(0.299) * rgb[..., 0] + np.float32(0.587) * rgb[..., 1] + np.float32(0.114) * rgb[..., 2]).astype(np.float32)
+    return np.repeat(np.repeat(y, 2, axis=0), 2, axis=1)
+
+
+def cpu_baseline(layers, plane, budget_s=15.0):
+    """Time the CPU oracle ("port": restatement of the reference algorithm, oracle/w2xc_oracle.c) on whole
+    512x512 blocks of the same plane, nJob = host cores.  Returns the cpu_baseline object."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    o = orc.Oracle(layers)
+    blk = np.ascontiguousarray(plane[:498, :498])   # pads to one full 512x512 block (498 + 2*7)
+    t0 = time.perf_counter()
+    o.convert(blk, block_splitting=False, njob=cores)
+    t1 = time.perf_counter() - t0
+    n = 1
+    total = t1
+    while total + t1 <= budget_s and n < 8:
+        y0 = (n * 498) % (plane.shape[0] - 498)
+        blk = np.ascontiguousarray(plane[y0:y0 + 498, 498:996])
+        t0 = time.perf_counter()
+        o.convert(blk, block_splitting=False, njob=cores)
+        total += time.perf_counter() - t0
+        n += 1
+    cnn_px = n * 498 * 498
+    return {
+        "value": round(cnn_px / 4.0 / total / 1e6, 6),
+        "unit": "Mpix/s (input-image pixels)",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d whole 512x512 blocks (498x498 useful CNN pixels each) of the same plane, nJob=%d std::thread-style "
+                  "output-plane partition, %.1f s; extrapolates to the plane because the reference's block-split "
+                  "path costs the same per block" % (n, cores, total),
+        "label": "CPU restatement of reference algorithm (OpenCV unavailable)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=1080, help="input frame height (CNN plane is 2x)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--band-rows", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as graft
+    from oracle import gen_model
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    w2xc = graft.load_package()
+    layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
+    ms = w2xc._ModelSet.from_layers(layers)
+    n_layers = ms.n_layers
+
+    plane = synth_frame_luma(seed=2 + rank, h=args.height, w=args.width)
+    H, W = plane.shape
+    d_in = torch.from_numpy(plane).cuda()
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream()
+    opts = w2xc.make_opts(device=local_rank, profile=1, band_rows=args.band_rows)
+
+    def step():
+        ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=opts)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ms.profile_reset(local_rank)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    layer_ms, launches = ms.profile_read(local_rank)
+    ok = bool(torch.isfinite(d_out).all().item())
+
+    if rank == 0:
+        in_px = args.height * args.width
+        value = world * in_px * args.steps / elapsed / 1e6
+        # dominant kernel: the layer with the most FLOPs
+        flops_layer = []
+        for l in range(n_layers):
+            cin, cout = ms.planes(l)
+            k = l + 1
+            oh, ow = H + 2 * (n_layers - k), W + 2 * (n_layers - k)   # whole-plane band
+            flops_layer.append(2 * 9 * cin * cout * oh * ow)
+        dom = int(np.argmax(flops_layer))
+        dom_launches = max(launches[dom], 1)
+        dom_ms = layer_ms[dom] / dom_launches
+        bands = dom_launches // max(args.steps, 1)
+        dom_flops = flops_layer[dom] / max(bands, 1) if bands > 1 else flops_layer[dom]
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        per_layer = []
+        for l in range(n_layers):
+            ms_l = layer_ms[l] / max(launches[l], 1) * max(launches[l] // max(args.steps, 1), 1)
+            cin, cout = ms.planes(l)
+            per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l), "planes": "%d->%d" % (cin, cout),
+                              "ms": round(ms_l, 4),
+                              "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None})
+        out = {
+            "metric": "Mpixels/sec end-to-end scale2.0x 7-layer conv",
+            "value": round(value, 4),
+            "unit": "Mpix/s (input-image pixels; CNN-plane pixels = 4x)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "scale2x_1080p: scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
+                                   "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
+                                   "planes resident in HBM" % (args.width, args.height, W, H),
+                       "cnn_plane": [H, W], "frames_per_step": world, "bands_per_frame": max(bands, 1),
+                       "sharding": "independent frames per rank, no collective on the data path"},
+            "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom), dom + 1) + ms.planes(dom)),
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops},
+            "layers": per_layer,
+            "output_finite": ok,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(layers, plane, args.cpu_budget)
+            out["speedup_vs_cpu"] = round(value / world / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

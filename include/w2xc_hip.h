@@ -1,0 +1,134 @@
+/*
+ * w2xc_hip.h -- C ABI of libw2xc_hip.so, the MI355X (gfx950) engine for the one hot path of
+ * WL-Amigo/waifu2x-converter-cpp v1:
+ *
+ *     w2xc::convertWithModels -> Model::filter -> Model::filterWorker
+ *     (/root/reference/src/convertRoutine.cpp:21-169, src/modelHandler.cpp:26-72,117-159)
+ *
+ * Plain pointers and sizes only: this is what a cgo/JNI/ctypes/C++ binding of the reference's
+ * API for this path binds to.  include/w2xc/modelHandler.hpp and convertRoutine.hpp re-expose the
+ * reference's exact C++ signatures (w2xc::Model, w2xc::modelUtility, w2xc::convertWithModels) on
+ * top of these entry points; INTEGRATION.md shows the swap.
+ *
+ * Every function returns W2XC_OK (0) or a negative W2XC_ERR_* code; w2xc_last_error() holds a
+ * message for the calling thread.  There is NO CPU fallback: if no HIP device is usable the
+ * compute calls fail with W2XC_ERR_HIP.
+ */
+#ifndef W2XC_HIP_H_
+#define W2XC_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2XC_OK               0
+#define W2XC_ERR_IO          -1   /* model file could not be opened (modelHandler.cpp:175-179)      */
+#define W2XC_ERR_JSON        -2   /* JSON parse / schema error       (modelHandler.cpp:181-187)      */
+#define W2XC_ERR_ARG         -3   /* bad argument (null pointer, non-positive size, bad stride ...) */
+#define W2XC_ERR_PLANES      -4   /* number of input planes mismatch (modelHandler.cpp:29-35)        */
+#define W2XC_ERR_HIP         -5   /* HIP runtime error / no device                                   */
+#define W2XC_ERR_UNSUPPORTED -6   /* kernel size != 3 (hpp:52-58 only demands square; see Q8)        */
+#define W2XC_ERR_NOMEM       -7
+
+/* One loaded model file == the reference's std::vector<std::unique_ptr<w2xc::Model>>
+ * (one w2xc::Model per conv layer, modelHandler.hpp:24-90). */
+typedef struct w2xc_model w2xc_model;
+
+#define W2XC_PRECISION_FP32 0   /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-f32 fma chains        */
+#define W2XC_PRECISION_BF16 1   /* bf16 operands, fp32 accumulate (reserved)        */
+
+#define W2XC_KERNEL_AUTO    0   /* MFMA implicit-GEMM where the layer shape allows                 */
+#define W2XC_KERNEL_DIRECT  1   /* reference-ordered direct conv on VALU (bit-exact vs the oracle) */
+
+typedef struct w2xc_opts {
+    int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */
+    int      precision;       /* W2XC_PRECISION_*                                                    */
+    int      kernel;          /* W2XC_KERNEL_*                                                       */
+    int      device;          /* device-pointer entry points: HIP device ordinal, -1 = current      */
+    unsigned device_mask;     /* host-pointer entry points: bit i = use device i; 0 = all devices   */
+    int      band_rows;       /* output rows per band (tile height); 0 = derive from workspace_mb   */
+    int      workspace_mb;    /* activation workspace budget per device in MiB; 0 = default (16384) */
+    int      profile;         /* 1 = bracket every layer launch with hipEvents (see below)          */
+    int      verbose;         /* 1 = print the reference's progress lines (convertRoutine.cpp:67)   */
+} w2xc_opts;
+
+/* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding). */
+void w2xc_opts_init(w2xc_opts *o);
+
+/* ---- model container (modelHandler.hpp:24-90, modelHandler.cpp:74-115,170-197) ------------- */
+
+/* == modelUtility::generateModelFromJSON (modelHandler.cpp:170-197).  The file is a JSON array of
+ * {kW,kH,nInputPlane,nOutputPlane,bias[nOut],weight[nOut][nIn][kH][kW]} objects
+ * (appendix/waifu2x-nocuda/export_model_nocuda.lua:12-19).  Numbers are parsed with strtod and
+ * weights narrowed double->float exactly like modelHandler.cpp:95-97; biases stay double. */
+int w2xc_model_load_json(const char *path, w2xc_model **out);
+
+/* Same container from arrays: weight[l] is [nout][nin][3][3] floats (index o*nin+i, :102),
+ * bias[l] is nout doubles.  Data is copied. */
+int w2xc_model_from_arrays(int n_layers, const int *nin, const int *nout,
+                           const float *const *weight, const double *const *bias, w2xc_model **out);
+
+void w2xc_model_free(w2xc_model *m);
+int  w2xc_model_layers(const w2xc_model *m);             /* models.size()                          */
+int  w2xc_model_nin(const w2xc_model *m, int layer);     /* Model::getNInputPlanes  (:18-20)        */
+int  w2xc_model_nout(const w2xc_model *m, int layer);    /* Model::getNOutputPlanes (:22-24)        */
+/* copy out one layer's weights ([nout][nin][3][3]) and biases; either pointer may be NULL.
+ * Backs Model::printWeightMatrix / printBiases (:229-242). */
+int  w2xc_model_get_layer(const w2xc_model *m, int layer, float *weight, double *bias);
+
+/* ---- modelUtility singleton knobs (modelHandler.hpp:92-113, .cpp:199-224) ------------------- */
+int  w2xc_set_jobs(int n);                    /* setNumberOfJobs: rejects n < 1 (:199-203)          */
+int  w2xc_get_jobs(void);                     /* default 4 (hpp:99)                                 */
+int  w2xc_set_block_size(int w, int h);       /* setBlockSize: rejects negatives (:209-213)         */
+int  w2xc_set_block_size_exp2(int exp);       /* setBlockSizeExp2Square (:215-220)                  */
+void w2xc_get_block_size(int *w, int *h);     /* default 512x512 (hpp:99)                           */
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* == w2xc::convertWithModels(inputPlane, outputPlane, models, blockSplitting)
+ * (convertRoutine.cpp:21-51).  `in`/`out` are HOST pointers to h rows of w floats, strides in
+ * bytes (a cv::Mat ROI's step).  out(y,x) = valid-conv CNN(replicate_pad(in, n_layers))(y,x):
+ * identical math per output pixel to both the unsplit path (:32-46) and the 512/498 block walk
+ * (:84-169), so `block_splitting` and the singleton block size do not change results and the
+ * engine bands the plane by its own workspace budget.  No clipping (Q2).  Uses every device in
+ * opts->device_mask: row bands are striped over devices, one host thread per device, no
+ * inter-device traffic.  opts may be NULL. */
+int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h,
+                       float *out, size_t out_stride_bytes, int block_splitting,
+                       const w2xc_opts *opts);
+
+/* Same contract with DEVICE pointers on device opts->device, enqueued on `hip_stream`
+ * (a hipStream_t; NULL = the null stream) and NOT synchronised on return.  Input and output
+ * stay resident in HBM: this is what bench.py times. */
+int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h,
+                              float *d_out, size_t out_stride_bytes, void *hip_stream,
+                              const w2xc_opts *opts);
+
+/* == Model::filter(inputPlanes, outputPlanes) for layer `layer` (modelHandler.cpp:26-72):
+ * n_in_planes host planes of h x w floats in, nout planes out, SAME size, per-layer
+ * BORDER_REPLICATE (:141-142), bias, LeakyReLU(0.1) (:147-152).  Returns W2XC_ERR_PLANES when
+ * n_in_planes != nInputPlanes (the reference returns false, :29-35). */
+int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *const *in_planes,
+                      size_t in_stride_bytes, int w, int h, float *const *out_planes,
+                      size_t out_stride_bytes, const w2xc_opts *opts);
+
+/* ---- measurement / introspection ------------------------------------------------------------ */
+
+/* With opts->profile = 1 every layer launch of the device entry point is bracketed by hipEvents
+ * on the launch stream.  After the stream has been synchronised, this returns for each layer the
+ * SUM of its launch durations (ms) and the number of launches since the last reset. */
+int  w2xc_profile_read(w2xc_model *m, int device, float *layer_ms, int *layer_launches, int n_layers);
+void w2xc_profile_reset(w2xc_model *m, int device);
+/* name of the kernel the engine picks for a layer (for matching rocprofv3 kernel traces) */
+const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_opts *opts);
+
+int w2xc_device_count(void);          /* hipGetDeviceCount, 0 when no device / no driver           */
+const char *w2xc_last_error(void);    /* thread-local message of the last failing call             */
+const char *w2xc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2XC_HIP_H_ */

@@ -1,0 +1,162 @@
+"""CPU tests of the drop-in boundary: libw2xc_hip.so loads and exports every symbol that
+include/w2xc_hip.h declares, the model container / JSON loader / modelUtility knobs behave like
+the reference's (src/modelHandler.{hpp,cpp}), and -- without a GPU -- the compute calls FAIL
+(no CPU fallback anywhere in the product path)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rand_plane, small_layers
+from oracle import gen_model, oracle as orc
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "w2xc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(w2xc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(w2xc):
+    names = header_functions()
+    assert len(names) >= 20
+    lib = C.CDLL(w2xc.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libw2xc_hip.so does not export %s" % n
+    assert set(names) == set(w2xc.ABI_SYMBOLS), "python binding and header disagree"
+    lib.w2xc_version.restype = C.c_char_p
+    assert b"gfx950" in lib.w2xc_version()
+
+
+def test_no_oracle_in_product_path():
+    """the product package must never import, link or execute anything under oracle/"""
+    pkg = os.path.join(ROOT, "waifu2x-converter-cpp_amd")
+    banned = re.compile(r"(import\s+oracle|from\s+oracle|w2xc_oracle|libw2xc_ref|oracle/|oracle\.py|_ref/)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not banned.search(text), "%s reaches into the oracle" % os.path.join(dirpath, f)
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "lib", "libw2xc_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "w2xc_ref" not in out
+
+
+def test_load_json_matches_reference_loader(w2xc, models_dir):
+    p = os.path.join(models_dir, "scale2.0x_model.json")
+    ms = w2xc._ModelSet.from_json(p)
+    want = orc.load_model_json(p)
+    assert ms.n_layers == 7
+    assert [ms.planes(l) for l in range(7)] == [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)]
+    for l, (nin, nout, w, b) in enumerate(want):
+        gi, go, gw, gb = ms.layer_arrays(l)
+        assert (gi, go) == (nin, nout)
+        assert np.array_equal(gw, w), "double->float narrowing differs in layer %d" % l
+        assert np.array_equal(gb, b)
+    ref = orc.RefBuild(p)   # the reference's own loader agrees on the topology
+    assert [ref.planes(l) for l in range(ref.nlayers)] == [ms.planes(l) for l in range(7)]
+
+
+def test_model_vector_semantics(w2xc, models_dir):
+    models = []
+    assert w2xc.modelUtility.generateModelFromJSON(os.path.join(models_dir, "noise1_model.json"), models)
+    assert len(models) == 7
+    assert models[0].getNInputPlanes() == 1 and models[0].getNOutputPlanes() == 32
+    assert models[6].getNInputPlanes() == 128 and models[6].getNOutputPlanes() == 1
+    # appending a second file extends the same vector, like the reference's push_back (:189-194)
+    assert w2xc.modelUtility.generateModelFromJSON(os.path.join(models_dir, "noise2_model.json"), models)
+    assert len(models) == 14
+
+
+def test_loader_errors(w2xc, tmp_path, capfd):
+    models = []
+    assert not w2xc.modelUtility.generateModelFromJSON(str(tmp_path / "missing.json"), models)   # :175-179
+    assert "couldn't open" in capfd.readouterr().err
+    bad = tmp_path / "bad.json"
+    bad.write_text('[{"kW":3,"kH":3,')
+    with pytest.raises(w2xc.W2xcError) as e:
+        w2xc._ModelSet.from_json(str(bad))
+    assert e.value.code == w2xc.ERR_JSON
+    nonsq = tmp_path / "nonsq.json"
+    nonsq.write_text('[{"kW":3,"kH":5,"nInputPlane":1,"nOutputPlane":1,"bias":[0],"weight":[[[[0,0,0],[0,0,0],[0,0,0]]]]}]')
+    with pytest.raises(w2xc.W2xcError) as e:
+        w2xc._ModelSet.from_json(str(nonsq))     # the reference exit(-1)s (hpp:52-58); the library reports
+    assert e.value.code == w2xc.ERR_UNSUPPORTED
+    short = tmp_path / "short.json"
+    short.write_text('[{"kW":3,"kH":3,"nInputPlane":2,"nOutputPlane":1,"bias":[0],"weight":[[[[0,0,0],[0,0,0],[0,0,0]]]]}]')
+    with pytest.raises(w2xc.W2xcError) as e:
+        w2xc._ModelSet.from_json(str(short))
+    assert e.value.code == w2xc.ERR_JSON
+    assert not models
+
+
+def test_json_number_forms(w2xc, tmp_path):
+    """strtod semantics (picojson.h:725-793): exponents, negative zero, long mantissas"""
+    p = tmp_path / "n.json"
+    p.write_text('[{"kW":3,"kH":3,"nInputPlane":1,"nOutputPlane":1,"bias":[-1.5e-3],'
+                 '"weight":[[[[1e-1, -0.0, 2.5E+1],[0.1000000000000000055511151231257827, 3, -7e-40],[1.17549435e-38, 16777217, 0.30000001192092896]]]]}]')
+    ms = w2xc._ModelSet.from_json(str(p))
+    _, _, w, b = ms.layer_arrays(0)
+    want = np.array([1e-1, -0.0, 2.5e1, 0.1, 3, -7e-40, 1.17549435e-38, 16777217, 0.30000001192092896], np.float64).astype(np.float32)
+    assert np.array_equal(w.ravel().view(np.uint32), want.view(np.uint32))
+    assert b[0] == -1.5e-3
+
+
+def test_model_utility_singleton(w2xc):
+    u = w2xc.modelUtility.getInstance()
+    assert u is w2xc.modelUtility.getInstance()
+    assert u.getNumberOfJobs() == 4                 # hpp:99
+    assert u.getBlockSize() == (512, 512)           # hpp:99
+    assert not u.setNumberOfJobs(0) and u.getNumberOfJobs() == 4     # cpp:200
+    assert u.setNumberOfJobs(8) and u.getNumberOfJobs() == 8
+    assert not u.setBlockSize((-1, 4)) and u.getBlockSize() == (512, 512)   # cpp:210
+    assert u.setBlockSizeExp2Square(8) and u.getBlockSize() == (256, 256)   # cpp:215-220
+    assert not u.setBlockSizeExp2Square(-1)
+    assert u.setBlockSize((512, 512)) and u.setNumberOfJobs(4)
+
+
+def test_opts_defaults(w2xc):
+    o = w2xc.make_opts()
+    assert o.struct_size == C.sizeof(w2xc.Opts)
+    assert (o.precision, o.kernel, o.device, o.device_mask, o.band_rows, o.profile) == (0, 0, -1, 0, 0, 0)
+
+
+def test_argument_validation(w2xc, noise1_layers):
+    ms = w2xc._ModelSet.from_layers(noise1_layers)
+    lib = w2xc.lib()
+    buf = np.zeros((4, 4), np.float32)
+    assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, 16, 0, 4, buf.ctypes.data, 16, 1, None) == w2xc.ERR_ARG
+    assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, 8, 4, 4, buf.ctypes.data, 16, 1, None) == w2xc.ERR_ARG
+    assert lib.w2xc_convert_plane(ms.handle, None, 16, 4, 4, buf.ctypes.data, 16, 1, None) == w2xc.ERR_ARG
+    with pytest.raises(w2xc.W2xcError) as e:
+        ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
+    assert e.value.code == w2xc.ERR_PLANES
+    assert ms.kernel_name(5) == "conv3x3_mfma" and ms.kernel_name(0) == "conv3x3_first" and ms.kernel_name(6) == "conv3x3_last"
+    assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
+
+
+def test_no_cpu_fallback_without_gpu(w2xc, noise1_layers):
+    """On a box without a HIP device the product path must fail, never compute on the CPU."""
+    if w2xc.device_count() > 0:
+        pytest.skip("a GPU is present; covered by the -m gpu tests")
+    ms = w2xc._ModelSet.from_layers(noise1_layers)
+    with pytest.raises(w2xc.W2xcError) as e:
+        ms.convert(rand_plane(8, 8, 0))
+    assert e.value.code == w2xc.ERR_HIP
+    out = w2xc.Mat()
+    models = [w2xc.Model(ms, i) for i in range(7)]
+    assert w2xc.convertWithModels(w2xc.Mat(rand_plane(8, 8, 0)), out, models) is False
+    assert out.array is None
+    outs = []
+    assert models[0].filter([w2xc.Mat(rand_plane(8, 8, 0))], outs) is False
+
+
+def test_arbitrary_model_lists_get_their_own_container(w2xc):
+    a = w2xc._ModelSet.from_layers(small_layers([1, 4, 4, 1], 3))
+    models = [w2xc.Model(a, i) for i in range(3)]
+    assert w2xc._set_of(models) is a
+    sub = w2xc._set_of(models[:2])
+    assert sub is not a and sub.n_layers == 2 and sub.planes(1) == (4, 4)
+    assert np.array_equal(sub.layer_arrays(1)[2], a.layer_arrays(1)[2])

@@ -1,0 +1,239 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bars:  conv3x3_direct (reference summation order, unfused mul/add) -- BIT-EXACT;
+       MFMA kernels (fp32, exact fma chains in a different order)  -- rtol 1e-4 (+atol 1e-5) per
+       BASELINE.json's north_star, and max-norm relative error <= 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ATOL, RTOL, assert_close, ramp_plane, rand_plane, small_layers
+from oracle import gen_model, oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu(w2xc):
+    assert w2xc.device_count() >= 1, "no HIP device visible: libw2xc_hip has no CPU fallback, -m gpu tests need an MI355X"
+    return w2xc
+
+
+def direct(w2xc):
+    return w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)
+
+
+# ---- Model::filter boundary, one layer at a time (each kernel kind in isolation) -----------------
+LAYER_SHAPES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1),
+                (3, 128), (128, 3), (64, 32), (128, 64), (32, 128), (3, 32), (64, 1), (32, 3),
+                (5, 7), (2, 33)]
+
+
+@pytest.mark.parametrize("cin,cout", LAYER_SHAPES)
+def test_layer_filter_direct_bit_exact(gpu, cin, cout):
+    layers = small_layers([cin, cout], 100 + cin * 7 + cout)
+    ms = gpu._ModelSet.from_layers(layers)
+    x = np.random.default_rng(cin + cout).standard_normal((cin, 21, 37)).astype(np.float32)
+    want = orc.Oracle(layers).filter(0, x)
+    got = ms.filter(0, x, direct(gpu))
+    assert ms.kernel_name(0, direct(gpu)) == "conv3x3_direct"
+    assert np.array_equal(got, want), "max abs diff %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("cin,cout", [s for s in LAYER_SHAPES if s not in [(5, 7), (2, 33)]])
+@pytest.mark.parametrize("h,w", [(21, 37), (8, 32), (9, 33), (1, 1), (40, 70)])
+def test_layer_filter_fast_kernels(gpu, cin, cout, h, w):
+    layers = small_layers([cin, cout], 200 + cin * 7 + cout)
+    ms = gpu._ModelSet.from_layers(layers)
+    assert ms.kernel_name(0) != "conv3x3_direct"
+    x = np.random.default_rng(cin * 3 + cout + h).standard_normal((cin, h, w)).astype(np.float32)
+    want = orc.Oracle(layers).filter(0, x)
+    got = ms.filter(0, x)
+    assert_close(got, want, "%s %d->%d %dx%d" % (ms.kernel_name(0), cin, cout, h, w))
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (1, 32), (128, 1)])
+def test_fast_kernels_orientation(gpu, cin, cout):
+    """transpose / tap-order detector: a single asymmetric tap and asymmetric plane<->plane map,
+    on a non-symmetric ramp (a symmetric kernel or image would hide a swapped row/col)."""
+    w = np.zeros((cout, cin, 3, 3), np.float32)
+    rng = np.random.default_rng(5)
+    for o in range(cout):
+        w[o, (o * 5 + 1) % cin, rng.integers(0, 3), rng.integers(0, 3)] = 1.0 + o / 64.0
+    b = np.linspace(-0.5, 0.5, cout)
+    layers = [(cin, cout, w, b.astype(np.float64))]
+    ms = gpu._ModelSet.from_layers(layers)
+    x = np.stack([ramp_plane(19, 45) * (1 + 0.1 * i) - 0.3 * i for i in range(cin)])
+    want = orc.Oracle(layers).filter(0, x)
+    got = ms.filter(0, x)
+    # one product per output: the MFMA result is exact up to the bias add
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+
+
+def test_filter_plane_count_mismatch(gpu, noise1_layers):
+    ms = gpu._ModelSet.from_layers(noise1_layers)
+    models = [gpu.Model(ms, i) for i in range(7)]
+    outs = ["stale"]
+    assert models[1].filter([gpu.Mat(rand_plane(8, 8, i)) for i in range(3)], outs) is False
+    assert outs == ["stale"]
+    assert models[0].filter([gpu.Mat(rand_plane(8, 8, 0))], outs) is True
+    assert len(outs) == 32 and outs[0].array.shape == (8, 8)
+
+
+# ---- convertWithModels ----------------------------------------------------------------------------
+def test_cfg1_noise1_256(gpu, noise1_layers):
+    """BASELINE.json configs[0]: noise1 topology on a 256x256 luma plane, vs the CPU convertRoutine."""
+    ms = gpu._ModelSet.from_layers(noise1_layers)
+    x = rand_plane(256, 256, 1)
+    o = orc.Oracle(noise1_layers)
+    want = o.convert(x, njob=8)
+    got = ms.convert(x)
+    assert_close(got, want, "cfg1")
+    # error budget against the fp64 truth: GPU error should be of the same class as the oracle's own
+    truth = o.convert_f64(x)
+    e_gpu, e_cpu = np.abs(got - truth).max(), np.abs(want - truth).max()
+    assert e_gpu <= max(4 * e_cpu, 2e-6), (e_gpu, e_cpu)
+
+
+def test_direct_path_is_bit_exact_end_to_end(gpu, noise1_layers):
+    ms = gpu._ModelSet.from_layers(noise1_layers)
+    x = rand_plane(70, 45, 2)
+    want = orc.Oracle(noise1_layers).convert(x)
+    got = ms.convert(x, opts=direct(gpu))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 9), (33, 65), (100, 31), (64, 200)])
+def test_odd_sizes(gpu, scale_layers, h, w):
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(h, w, h * 1000 + w)
+    assert_close(ms.convert(x), orc.Oracle(scale_layers).convert(x), "%dx%d" % (h, w))
+
+
+@pytest.mark.parametrize("band", [1, 5, 32, 64])
+def test_banding_does_not_change_results(gpu, scale_layers, band):
+    """any tiling with an n-px halo gives the same math per output pixel -- bit-exact
+    between band sizes on the GPU (same kernels, same per-pixel summation order)."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(90, 75, 7)
+    whole = ms.convert(x, opts=gpu.make_opts(band_rows=90))
+    banded = ms.convert(x, opts=gpu.make_opts(band_rows=band))
+    assert np.array_equal(whole, banded)
+    tiny_ws = ms.convert(x, opts=gpu.make_opts(workspace_mb=1))   # workspace-derived banding
+    assert np.array_equal(whole, tiny_ws)
+
+
+def test_strided_roi_in_and_out(gpu, noise1_layers):
+    """cv::Mat ROIs: honour `step` on both sides"""
+    ms = gpu._ModelSet.from_layers(noise1_layers)
+    big = rand_plane(80, 120, 8)
+    roi = big[10:60, 20:90]
+    assert not roi.flags["C_CONTIGUOUS"]
+    want = orc.Oracle(noise1_layers).convert(np.ascontiguousarray(roi))
+    assert_close(ms.convert(roi), want, "strided in")
+    lib = gpu.lib()
+    outbig = np.full((60, 100), -7.0, np.float32)
+    outroi = outbig[5:55, 10:80]
+    rc = lib.w2xc_convert_plane(ms.handle, roi.ctypes.data, roi.strides[0], 70, 50, outroi.ctypes.data,
+                                outroi.strides[0], 1, None)
+    assert rc == 0, gpu.last_error()
+    assert_close(outroi, want, "strided out")
+    mask = np.ones_like(outbig, bool)
+    mask[5:55, 10:80] = False
+    assert np.all(outbig[mask] == -7.0), "wrote outside the output ROI"
+
+
+def test_reference_api_mirror(gpu, models_dir):
+    """reads like the reference's main.cpp:83-98"""
+    models = []
+    assert gpu.modelUtility.generateModelFromJSON(os.path.join(models_dir, "noise1_model.json"), models)
+    gpu.modelUtility.getInstance().setNumberOfJobs(4)
+    y = rand_plane(48, 64, 9)
+    out = gpu.Mat()
+    assert gpu.convertWithModels(gpu.Mat(y), out, models)
+    want = orc.Oracle.from_json(os.path.join(models_dir, "noise1_model.json")).convert(y)
+    assert_close(out.array, want, "api mirror")
+    assert gpu.convertWithModels(gpu.Mat(y), out, models, False)      # blockSplitting=false: same result (I2)
+    assert_close(out.array, want, "api mirror unsplit")
+    # a sub-list of layers is a valid model vector too (test.cpp drives Model::filter directly)
+    out2 = gpu.Mat()
+    assert gpu.convertWithModels(gpu.Mat(y), out2, models[:1]) is True   # 1->32: returns outputPlanes[0]
+    sub = orc.Oracle(orc.load_model_json(os.path.join(models_dir, "noise1_model.json"))[:1])
+    assert_close(out2.array, sub.convert(y), "single-layer vector")
+
+
+def test_golden_fixtures_on_gpu(gpu):
+    """fixtures produced by the reference's own code (oracle/_ref), see tests/golden/make_golden.py"""
+    for f in sorted(os.listdir(GOLDEN)):
+        if not f.endswith(".npz"):
+            continue
+        g = np.load(os.path.join(GOLDEN, f))
+        layers = gen_model.synth_layers([int(v) for v in g["planes"]], int(g["seed"]))
+        ms = gpu._ModelSet.from_layers(layers)
+        assert_close(ms.convert(g["input"]), g["output"], f)
+        assert np.array_equal(ms.convert(g["input"], opts=direct(gpu)), g["output"]), f
+
+
+def test_device_pointer_entry_point(gpu, scale_layers):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(120, 200, 11)
+    want = orc.Oracle(scale_layers).convert(x)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros_like(d_in)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    o = gpu.make_opts(device=0, profile=1)
+    ms.profile_reset(0)
+    ms.convert_device(d_in.data_ptr(), 200 * 4, 200, 120, d_out.data_ptr(), 200 * 4, stream=side.cuda_stream, opts=o)
+    side.synchronize()
+    assert_close(d_out.cpu().numpy(), want, "device entry")
+    ms_t, launches = ms.profile_read(0)
+    assert launches == [1] * 7 and all(t > 0 for t in ms_t)
+
+
+def test_wide_model_cfg5_boundary(gpu):
+    """BASELINE.json configs[4] shape (3->128->...->3) goes through Model::filter (convertWithModels
+    can only push one plane, convertRoutine.cpp:63-64)."""
+    layers = gen_model.synth_layers(gen_model.TOPOLOGY_WIDE, gen_model.SEEDS["wide"])
+    ms = gpu._ModelSet.from_layers(layers)
+    o = orc.Oracle(layers)
+    x = np.random.default_rng(12).random((3, 24, 40), dtype=np.float32)
+    a, b = x, x
+    for l in range(7):
+        a = ms.filter(l, a)
+        b = o.filter(l, b, njob=8)
+    assert_close(a, b, "wide chain")
+    with pytest.raises(gpu.W2xcError) as e:
+        ms.convert(x[0])
+    assert e.value.code == gpu.ERR_PLANES
+
+
+# ---- full-size properties (BASELINE.json configs[1]: 1920x1080 -> CNN plane 2160x3840) --------------
+def test_full_size_patches_and_band_invariance(gpu, scale_layers):
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    rng = np.random.default_rng(2)
+    small = rng.random((1080, 1920), dtype=np.float32)
+    plane = np.repeat(np.repeat(small, 2, axis=0), 2, axis=1)       # nearest 2x (main.cpp:132-140)
+    got = ms.convert(plane)
+    assert got.shape == (2160, 3840) and np.isfinite(got).all()
+    o = orc.Oracle(scale_layers)
+    H, W = plane.shape
+    # oracle on patches: corners (replicate border), edges, a band seam, interior
+    spots = [(0, 0), (0, W - 48), (H - 48, 0), (H - 48, W - 48), (1000, 2000), (0, 1900), (1056, 0), (517, 3001)]
+    for (y, x) in spots:
+        ph, pw = 48, 48
+        y0, y1, x0, x1 = max(0, y - 7), min(H, y + ph + 7), max(0, x - 7), min(W, x + pw + 7)
+        # a crop that touches the plane border keeps replicate semantics there; interior crop edges are
+        # discarded (7-px rim) -- exactly the reference's block-split argument (convertRoutine.cpp:84-169)
+        sub = o.convert(np.ascontiguousarray(plane[y0:y1, x0:x1]), block_splitting=False, njob=8)
+        want = sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw]
+        assert_close(got[y:y + ph, x:x + pw], want, "patch (%d,%d)" % (y, x))
+    banded = ms.convert(plane, opts=gpu.make_opts(band_rows=500))
+    assert np.array_equal(got, banded)

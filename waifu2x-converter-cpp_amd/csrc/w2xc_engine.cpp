@@ -1,0 +1,698 @@
+// w2xc_engine.cpp -- C ABI of libw2xc_hip.so (include/w2xc_hip.h): model container + JSON
+// loader (the reference's Model / modelUtility, src/modelHandler.{hpp,cpp}), and the band loop that
+// replaces convertWithModels / convertWithModelsBasic / convertWithModelsBlockSplit
+// (src/convertRoutine.cpp:21-169) on MI355X.
+//
+// Data layout in HBM: activations between layers are NHWC fp32 (pixel stride = plane count), two
+// ping-pong workspaces per device sized for one band; layer 1 reads the caller's planar plane with
+// clamp-to-edge addressing (= copyMakeBorder, convertRoutine.cpp:35,96) and the last layer writes
+// the planar output rows in place (= crop + stitch, :40-46,143-161).  A band is `band_rows`
+// output rows x full width; layer k of n computes (rows + 2(n-k)) x (w + 2(n-k)) pixels (valid
+// conv on the haloed band -- SURVEY invariants I1/I2).
+//
+// There is no CPU fallback: without a HIP device every compute entry point fails.
+#include "../../include/w2xc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "json_min.hpp"
+#include "w2xc_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(W2XC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct HostLayer {
+    int nin = 0, nout = 0;
+    std::vector<float> w;       // [nout][nin][3][3], index o*nin+i (modelHandler.cpp:102)
+    std::vector<double> bias;   // modelHandler.cpp:109-112 keeps doubles
+};
+
+struct DevLayer {
+    W2xcKernelKind fast = W2XC_K_DIRECT;
+    float *w_fast = nullptr;
+    float *w_direct = nullptr;
+    float *bias = nullptr;
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int layer;
+};
+
+struct DevCtx {
+    int device = 0;
+    std::vector<DevLayer> layers;
+    float *ws[2] = {nullptr, nullptr};
+    size_t ws_floats[2] = {0, 0};
+    std::vector<ProfEvent> pending, pool;
+    std::vector<double> layer_ms;
+    std::vector<int> layer_launches;
+    std::mutex mu;
+
+    ~DevCtx()
+    {
+        int prev = 0;
+        hipGetDevice(&prev);
+        hipSetDevice(device);
+        for (auto &l : layers) {
+            if (l.w_fast) hipFree(l.w_fast);
+            if (l.w_direct) hipFree(l.w_direct);
+            if (l.bias) hipFree(l.bias);
+        }
+        for (int i = 0; i < 2; i++)
+            if (ws[i]) hipFree(ws[i]);
+        for (auto &e : pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        for (auto &e : pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        hipSetDevice(prev);
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        ok = (dev == prev) || hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) hipSetDevice(prev);
+    }
+};
+
+// modelUtility singleton state (modelHandler.hpp:92-100)
+std::mutex g_util_mu;
+int g_njob = 4;
+int g_block_w = 512, g_block_h = 512;
+
+}  // namespace
+
+struct w2xc_model {
+    std::vector<HostLayer> layers;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DevCtx>> ctx;
+};
+
+namespace {
+
+w2xc_opts resolve_opts(const w2xc_opts *o)
+{
+    w2xc_opts r;
+    w2xc_opts_init(&r);
+    if (o) {
+        size_t n = o->struct_size > 0 && (size_t)o->struct_size < sizeof(w2xc_opts) ? (size_t)o->struct_size : sizeof(w2xc_opts);
+        memcpy(&r, o, n);
+        r.struct_size = (int)sizeof(w2xc_opts);
+    }
+    return r;
+}
+
+W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
+{
+    if (o.kernel == W2XC_KERNEL_DIRECT) return W2XC_K_DIRECT;
+    return w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout);
+}
+
+int upload(const std::vector<float> &h, float **d)
+{
+    HIP_TRY(hipMalloc((void **)d, std::max<size_t>(h.size(), 1) * sizeof(float)));
+    HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return W2XC_OK;
+}
+
+// per-(model, device) context: packed weights + biases resident in HBM; created on first use
+int get_ctx(w2xc_model *m, int device, DevCtx **out)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    auto it = m->ctx.find(device);
+    if (it != m->ctx.end()) { *out = it->second.get(); return W2XC_OK; }
+    std::unique_ptr<DevCtx> c(new DevCtx());
+    c->device = device;
+    c->layers.resize(m->layers.size());
+    c->layer_ms.assign(m->layers.size(), 0.0);
+    c->layer_launches.assign(m->layers.size(), 0);
+    for (size_t l = 0; l < m->layers.size(); l++) {
+        const HostLayer &hl = m->layers[l];
+        DevLayer &dl = c->layers[l];
+        dl.fast = w2xc_pick_kernel(hl.nin, hl.nout);
+        std::vector<float> pk(w2xc_packed_weight_floats(W2XC_K_DIRECT, hl.nin, hl.nout));
+        w2xc_pack_weights(W2XC_K_DIRECT, hl.nin, hl.nout, hl.w.data(), pk.data());
+        int rc = upload(pk, &dl.w_direct);
+        if (rc) return rc;
+        if (dl.fast != W2XC_K_DIRECT) {
+            pk.assign(w2xc_packed_weight_floats(dl.fast, hl.nin, hl.nout), 0.f);
+            w2xc_pack_weights(dl.fast, hl.nin, hl.nout, hl.w.data(), pk.data());
+            rc = upload(pk, &dl.w_fast);
+            if (rc) return rc;
+        }
+        std::vector<float> bf(hl.nout);
+        for (int o = 0; o < hl.nout; o++) bf[o] = (float)hl.bias[o];   // cv::add(UMat, double) narrows to the array depth
+        rc = upload(bf, &dl.bias);
+        if (rc) return rc;
+    }
+    *out = c.get();
+    m->ctx[device] = std::move(c);
+    return W2XC_OK;
+}
+
+int ensure_ws(DevCtx *c, int which, size_t floats)
+{
+    if (c->ws_floats[which] >= floats) return W2XC_OK;
+    if (c->ws[which]) {
+        HIP_TRY(hipDeviceSynchronize());   // earlier launches may still use the old buffer
+        HIP_TRY(hipFree(c->ws[which]));
+        c->ws[which] = nullptr;
+        c->ws_floats[which] = 0;
+    }
+    hipError_t e = hipMalloc((void **)&c->ws[which], floats * sizeof(float));
+    if (e != hipSuccess) return fail(W2XC_ERR_NOMEM, "hipMalloc(%zu MiB) for the activation workspace failed: %s", (floats * 4) >> 20, hipGetErrorString(e));
+    c->ws_floats[which] = floats;
+    return W2XC_OK;
+}
+
+int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
+{
+    if (!c->pool.empty()) { *ev = c->pool.back(); c->pool.pop_back(); }
+    else {
+        HIP_TRY(hipEventCreate(&ev->a));
+        HIP_TRY(hipEventCreate(&ev->b));
+    }
+    ev->layer = layer;
+    HIP_TRY(hipEventRecord(ev->a, st));
+    return W2XC_OK;
+}
+
+int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, bool profile)
+{
+    const DevLayer &dl = c->layers[l];
+    d.cin = m->layers[l].nin;
+    d.cout = m->layers[l].nout;
+    d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
+    d.bias = dl.bias;
+    ProfEvent ev;
+    if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
+    hipError_t e = w2xc_launch_conv(kind, d, st);
+    if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
+    if (profile) {
+        HIP_TRY(hipEventRecord(ev.b, st));
+        c->pending.push_back(ev);
+    }
+    return W2XC_OK;
+}
+
+// Output rows [ra, rb) of convertWithModels on an h-row plane of which `d_in` holds rows
+// [vy0, vy0+vh) -- every row in [ra-n, rb+n) clipped to the plane must be inside the view.
+int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,
+             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o)
+{
+    const int n = (int)m->layers.size();
+    if (n == 0) return fail(W2XC_ERR_ARG, "model has no layers");
+    if (m->layers[0].nin != 1)   // convertWithModelsBasic pushes exactly one plane (convertRoutine.cpp:63-64)
+        return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n1,%d", m->layers[0].nin);
+    for (int l = 1; l < n; l++)
+        if (m->layers[l].nin != m->layers[l - 1].nout)
+            return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
+    if (o.precision != W2XC_PRECISION_FP32) return fail(W2XC_ERR_UNSUPPORTED, "only W2XC_PRECISION_FP32 is implemented");
+
+    // floats per band row for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
+    auto ws_need = [&](int rows, size_t need[2]) {
+        need[0] = need[1] = 0;
+        for (int k = 1; k <= n; k++) {
+            if (k == n && m->layers[n - 1].nout == 1) break;   // written straight to d_out
+            const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
+            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * m->layers[k - 1].nout);
+        }
+    };
+    int band = o.band_rows;
+    const int total = rb - ra;
+    if (band <= 0) {
+        const size_t budget = (size_t)(o.workspace_mb > 0 ? o.workspace_mb : 16384) << 20;
+        size_t need[2];
+        ws_need(total, need);
+        if ((need[0] + need[1]) * sizeof(float) <= budget) band = total;
+        else {
+            // bytes grow linearly in rows: solve on two probes
+            size_t n1[2], n2[2];
+            ws_need(1, n1);
+            ws_need(2, n2);
+            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1])) * sizeof(float);
+            const double base = (double)(n1[0] + n1[1]) * sizeof(float) - per_row;
+            band = (int)std::floor(((double)budget - base) / per_row);
+            if (band < 1) band = 1;
+            const int nb = (total + band - 1) / band;
+            band = (total + nb - 1) / nb;   // equalise
+        }
+    }
+    band = std::min(band, total);
+    {
+        size_t need[2];
+        ws_need(band, need);
+        for (int i = 0; i < 2; i++)
+            if (need[i]) { int rc = ensure_ws(c, i, need[i]); if (rc) return rc; }
+    }
+
+    for (int y0 = ra; y0 < rb; y0 += band) {
+        const int y1 = std::min(rb, y0 + band);
+        const float *src = d_in;
+        long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = 0;
+        int src_h = vh, src_w = w;
+        for (int k = 1; k <= n; k++) {
+            if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
+            const HostLayer &hl = m->layers[k - 1];
+            W2xcConvDesc d;
+            memset(&d, 0, sizeof d);
+            d.in = src; d.in_rs = src_rs; d.in_ps = src_ps; d.in_cs = src_cs;
+            d.in_h = src_h; d.in_w = src_w;
+            d.out_h = (y1 - y0) + 2 * (n - k);
+            d.out_w = w + 2 * (n - k);
+            d.off_y = k == 1 ? (y0 - n - vy0) : 0;
+            d.off_x = k == 1 ? -n : 0;
+            const bool direct_out = (k == n && hl.nout == 1);
+            if (direct_out) {
+                d.out = d_out + (size_t)(y0 - ra) * out_stride_f;
+                d.out_rs = (long long)out_stride_f; d.out_ps = 1; d.out_cs = 0;
+            } else {
+                d.out = c->ws[(k - 1) & 1];
+                d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
+            }
+            int rc = launch_layer(c, m, k - 1, layer_kind(m, k - 1, o), d, st, o.profile != 0);
+            if (rc) return rc;
+            if (k == n && !direct_out) {
+                // outputPlanes[0] of a multi-plane last layer (convertRoutine.cpp:78)
+                hipError_t e = w2xc_launch_repack(d.out, d.out_rs, d.out_ps, 1, d_out + (size_t)(y0 - ra) * out_stride_f,
+                                                  (long long)out_stride_f, 1, 0, d.out_h, d.out_w, 1, st);
+                if (e != hipSuccess) return fail(W2XC_ERR_HIP, "repack launch failed: %s", hipGetErrorString(e));
+            }
+            src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs;
+            src_h = d.out_h; src_w = d.out_w;
+        }
+    }
+    return W2XC_OK;
+}
+
+int check_plane_args(const w2xc_model *m, const void *in, size_t in_stride, int w, int h, const void *out, size_t out_stride)
+{
+    if (!m || !in || !out) return fail(W2XC_ERR_ARG, "null argument");
+    if (w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "plane size must be positive (got %dx%d)", w, h);
+    if (in_stride < (size_t)w * 4 || out_stride < (size_t)w * 4 || (in_stride & 3) || (out_stride & 3))
+        return fail(W2XC_ERR_ARG, "row strides must be multiples of 4 bytes and >= 4*w");
+    return W2XC_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+void w2xc_opts_init(w2xc_opts *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (int)sizeof(w2xc_opts);
+    o->precision = W2XC_PRECISION_FP32;
+    o->kernel = W2XC_KERNEL_AUTO;
+    o->device = -1;
+}
+
+const char *w2xc_last_error(void) { return g_last_error.c_str(); }
+const char *w2xc_version(void) { return "w2xc_hip 0.1 (gfx950)"; }
+
+int w2xc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- model container ---------------------------------------------------------------------------
+int w2xc_model_from_arrays(int n_layers, const int *nin, const int *nout, const float *const *weight,
+                           const double *const *bias, w2xc_model **out)
+{
+    if (!out || n_layers <= 0 || !nin || !nout || !weight || !bias) return fail(W2XC_ERR_ARG, "bad argument");
+    std::unique_ptr<w2xc_model> m(new w2xc_model());
+    m->layers.resize(n_layers);
+    for (int l = 0; l < n_layers; l++) {
+        if (nin[l] <= 0 || nout[l] <= 0 || !weight[l] || !bias[l]) return fail(W2XC_ERR_ARG, "bad layer %d", l);
+        HostLayer &hl = m->layers[l];
+        hl.nin = nin[l];
+        hl.nout = nout[l];
+        hl.w.assign(weight[l], weight[l] + (size_t)nin[l] * nout[l] * 9);
+        hl.bias.assign(bias[l], bias[l] + nout[l]);
+    }
+    *out = m.release();
+    return W2XC_OK;
+}
+
+int w2xc_model_load_json(const char *path, w2xc_model **out)
+{
+    if (!path || !out) return fail(W2XC_ERR_ARG, "null argument");
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) {
+        std::cerr << "Error : couldn't open " << path << std::endl;   // modelHandler.cpp:176-178
+        return fail(W2XC_ERR_IO, "Error : couldn't open %s", path);
+    }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string text = ss.str();   // c_str() is NUL-terminated: strtod cannot overrun
+    jsonmin::Value root;
+    std::string err;
+    jsonmin::Parser p(text.c_str(), text.c_str() + text.size());
+    if (!p.parse(root, err)) {
+        std::cerr << "Error : JSON Error : " << err << std::endl;      // modelHandler.cpp:183-186
+        return fail(W2XC_ERR_JSON, "Error : JSON Error : %s", err.c_str());
+    }
+    if (!root.is_array() || root.arr.empty()) return fail(W2XC_ERR_JSON, "model file is not a non-empty JSON array of layers");
+    std::unique_ptr<w2xc_model> m(new w2xc_model());
+    for (size_t l = 0; l < root.arr.size(); l++) {   // one Model per element (:189-194)
+        const jsonmin::Value &o = root.arr[l];
+        if (!o.is_object()) return fail(W2XC_ERR_JSON, "layer %zu is not an object", l);
+        const jsonmin::Value *nip = o.find("nInputPlane"), *nop = o.find("nOutputPlane"), *kw = o.find("kW"),
+                             *kh = o.find("kH"), *wv = o.find("weight"), *bv = o.find("bias");
+        if (!nip || !nop || !kw || !kh || !wv || !bv || !nip->is_number() || !nop->is_number() || !kw->is_number() ||
+            !kh->is_number() || !wv->is_array() || !bv->is_array())
+            return fail(W2XC_ERR_JSON, "layer %zu lacks one of nInputPlane/nOutputPlane/kW/kH/weight/bias", l);
+        HostLayer hl;
+        hl.nin = (int)nip->num;     // static_cast<int>(double), modelHandler.hpp:50-51
+        hl.nout = (int)nop->num;
+        const int ks = (int)kw->num;
+        if (ks != (int)kh->num) {   // the reference exit(-1)s here (hpp:52-58); a library reports it
+            std::cerr << "Error : Model-Constructor : \nkernel in model is not square.\nstop." << std::endl;
+            return fail(W2XC_ERR_UNSUPPORTED, "kernel in model is not square");
+        }
+        if (ks != 3) return fail(W2XC_ERR_UNSUPPORTED, "layer %zu: kernel size %d; only 3x3 is supported (convertWithModels pads by the layer count, which assumes 3x3)", l, ks);
+        if (hl.nin <= 0 || hl.nout <= 0) return fail(W2XC_ERR_JSON, "layer %zu: bad plane counts", l);
+        if ((int)wv->arr.size() != hl.nout || (int)bv->arr.size() < hl.nout)
+            return fail(W2XC_ERR_JSON, "layer %zu: weight/bias outer size does not match nOutputPlane", l);
+        hl.w.resize((size_t)hl.nout * hl.nin * 9);
+        hl.bias.resize(hl.nout);
+        for (int oo = 0; oo < hl.nout; oo++) {
+            const jsonmin::Value &wi = wv->arr[oo];
+            if (!wi.is_array() || (int)wi.arr.size() != hl.nin) return fail(W2XC_ERR_JSON, "layer %zu: weight[%d] size != nInputPlane", l, oo);
+            for (int i = 0; i < hl.nin; i++) {
+                const jsonmin::Value &km = wi.arr[i];
+                if (!km.is_array() || (int)km.arr.size() < ks) return fail(W2XC_ERR_JSON, "layer %zu: weight[%d][%d] is not a %dx%d matrix", l, oo, i, ks, ks);
+                for (int r = 0; r < ks; r++) {
+                    const jsonmin::Value &row = km.arr[r];
+                    if (!row.is_array() || (int)row.arr.size() < ks) return fail(W2XC_ERR_JSON, "layer %zu: weight[%d][%d][%d] too short", l, oo, i, r);
+                    for (int cidx = 0; cidx < ks; cidx++) {
+                        if (!row.arr[cidx].is_number()) return fail(W2XC_ERR_JSON, "layer %zu: non-numeric weight", l);
+                        hl.w[((size_t)oo * hl.nin + i) * 9 + r * 3 + cidx] = (float)row.arr[cidx].num;   // double -> float, :95-97
+                    }
+                }
+            }
+            if (!bv->arr[oo].is_number()) return fail(W2XC_ERR_JSON, "layer %zu: non-numeric bias", l);
+            hl.bias[oo] = bv->arr[oo].num;   // stays double, :109-112
+        }
+        m->layers.push_back(std::move(hl));
+    }
+    *out = m.release();
+    return W2XC_OK;
+}
+
+void w2xc_model_free(w2xc_model *m) { delete m; }
+int w2xc_model_layers(const w2xc_model *m) { return m ? (int)m->layers.size() : 0; }
+int w2xc_model_nin(const w2xc_model *m, int l) { return (m && l >= 0 && l < (int)m->layers.size()) ? m->layers[l].nin : -1; }
+int w2xc_model_nout(const w2xc_model *m, int l) { return (m && l >= 0 && l < (int)m->layers.size()) ? m->layers[l].nout : -1; }
+
+int w2xc_model_get_layer(const w2xc_model *m, int l, float *weight, double *bias)
+{
+    if (!m || l < 0 || l >= (int)m->layers.size()) return fail(W2XC_ERR_ARG, "bad layer index");
+    const HostLayer &hl = m->layers[l];
+    if (weight) memcpy(weight, hl.w.data(), hl.w.size() * sizeof(float));
+    if (bias) memcpy(bias, hl.bias.data(), hl.bias.size() * sizeof(double));
+    return W2XC_OK;
+}
+
+// ---- modelUtility knobs --------------------------------------------------------------------------
+int w2xc_set_jobs(int n)
+{
+    if (n < 1) return W2XC_ERR_ARG;   // modelHandler.cpp:200
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    g_njob = n;
+    return W2XC_OK;
+}
+int w2xc_get_jobs(void) { std::lock_guard<std::mutex> lk(g_util_mu); return g_njob; }
+int w2xc_set_block_size(int w, int h)
+{
+    if (w < 0 || h < 0) return W2XC_ERR_ARG;   // :210
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    g_block_w = w; g_block_h = h;
+    return W2XC_OK;
+}
+int w2xc_set_block_size_exp2(int exp)
+{
+    if (exp < 0 || exp > 30) return W2XC_ERR_ARG;   // :216
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    g_block_w = g_block_h = 1 << exp;
+    return W2XC_OK;
+}
+void w2xc_get_block_size(int *w, int *h)
+{
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    if (w) *w = g_block_w;
+    if (h) *h = g_block_h;
+}
+
+// ---- hot path -------------------------------------------------------------------------------------
+int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h, float *d_out,
+                              size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts)
+{
+    int rc = check_plane_args(m, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes);
+    if (rc) return rc;
+    const w2xc_opts o = resolve_opts(opts);
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o);
+}
+
+int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
+                       size_t out_stride_bytes, int block_splitting, const w2xc_opts *opts)
+{
+    (void)block_splitting;   // results do not depend on the reference's block split
+    int rc = check_plane_args(m, in, in_stride_bytes, w, h, out, out_stride_bytes);
+    if (rc) return rc;
+    const w2xc_opts o = resolve_opts(opts);
+    const int ndev_all = w2xc_device_count();
+    if (ndev_all <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
+    std::vector<int> devs;
+    for (int d = 0; d < ndev_all && d < 32; d++)
+        if (o.device_mask == 0 || (o.device_mask >> d) & 1u) devs.push_back(d);
+    if (devs.empty()) return fail(W2XC_ERR_ARG, "device_mask 0x%x selects no available device (%d present)", o.device_mask, ndev_all);
+    const int n = (int)m->layers.size();
+    int nd = (int)devs.size();
+    if (nd > h) nd = h;
+
+    std::vector<int> rcs(nd, W2XC_OK);
+    std::vector<std::string> errs(nd);
+    auto worker = [&](int t) {
+        // contiguous row band [ra, rb) of the plane for device t: independent, no exchange
+        const int ra = (int)((long long)h * t / nd), rb = (int)((long long)h * (t + 1) / nd);
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(devs[t]));
+            DevCtx *c = nullptr;
+            int r = get_ctx(m, devs[t], &c);
+            if (r) return r;
+            const int vy0 = std::max(0, ra - n), vy1 = std::min(h, rb + n);
+            const int vh = vy1 - vy0;
+            float *d_in = nullptr, *d_out = nullptr;
+            hipStream_t st = nullptr;
+            HIP_TRY(hipStreamCreate(&st));
+            HIP_TRY(hipMalloc((void **)&d_in, (size_t)vh * w * sizeof(float)));
+            HIP_TRY(hipMalloc((void **)&d_out, (size_t)(rb - ra) * w * sizeof(float)));
+            HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)w * 4, (const char *)in + (size_t)vy0 * in_stride_bytes, in_stride_bytes,
+                                     (size_t)w * 4, vh, hipMemcpyHostToDevice, st));
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                r = run_rows(m, c, d_in, w, vh, vy0, w, ra, rb, d_out, w, st, o);
+            }
+            if (r == W2XC_OK) {
+                HIP_TRY(hipMemcpy2DAsync((char *)out + (size_t)ra * out_stride_bytes, out_stride_bytes, d_out, (size_t)w * 4,
+                                         (size_t)w * 4, rb - ra, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            } else {
+                hipStreamSynchronize(st);
+            }
+            hipFree(d_in);
+            hipFree(d_out);
+            hipStreamDestroy(st);
+            return r;
+        };
+        rcs[t] = body();
+        if (rcs[t]) errs[t] = g_last_error;
+    };
+    if (nd == 1) {
+        int prev = 0;
+        hipGetDevice(&prev);
+        worker(0);
+        hipSetDevice(prev);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nd; t++) th.emplace_back(worker, t);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < nd; t++)
+        if (rcs[t]) { g_last_error = errs[t]; std::cerr << errs[t] << std::endl; return rcs[t]; }
+    return W2XC_OK;
+}
+
+int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *const *in_planes, size_t in_stride_bytes,
+                      int w, int h, float *const *out_planes, size_t out_stride_bytes, const w2xc_opts *opts)
+{
+    if (!m || layer < 0 || layer >= (int)m->layers.size()) return fail(W2XC_ERR_ARG, "bad model/layer");
+    const HostLayer &hl = m->layers[layer];
+    if (n_in_planes != hl.nin) {   // modelHandler.cpp:29-35
+        std::cerr << "Error : Model-filter : \nnumber of input planes mismatch." << std::endl;
+        std::cerr << n_in_planes << "," << hl.nin << std::endl;
+        return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", n_in_planes, hl.nin);
+    }
+    if (!in_planes || !out_planes || w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "bad argument");
+    if (in_stride_bytes < (size_t)w * 4 || out_stride_bytes < (size_t)w * 4) return fail(W2XC_ERR_ARG, "bad stride");
+    const w2xc_opts o = resolve_opts(opts);
+    if (w2xc_device_count() <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    int rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+
+    const size_t px = (size_t)w * h;
+    float *p_in = nullptr, *p_out = nullptr, *n_in = nullptr, *n_out = nullptr;
+    auto cleanup = [&]() { hipFree(p_in); hipFree(p_out); hipFree(n_in); hipFree(n_out); };
+    auto body = [&]() -> int {
+        const W2xcKernelKind kind = layer_kind(m, layer, o);
+        const bool nhwc_in = (kind == W2XC_K_MFMA || kind == W2XC_K_LAST);
+        const bool nhwc_out = (kind == W2XC_K_MFMA || kind == W2XC_K_FIRST);
+        HIP_TRY(hipMalloc((void **)&p_in, px * hl.nin * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&p_out, px * hl.nout * sizeof(float)));
+        for (int i = 0; i < hl.nin; i++)
+            HIP_TRY(hipMemcpy2D(p_in + px * i, (size_t)w * 4, in_planes[i], in_stride_bytes, (size_t)w * 4, h, hipMemcpyHostToDevice));
+        W2xcConvDesc d;
+        memset(&d, 0, sizeof d);
+        d.in_h = d.out_h = h;
+        d.in_w = d.out_w = w;
+        d.off_y = d.off_x = -1;   // same-size conv, BORDER_REPLICATE via clamped loads (:141-142)
+        if (nhwc_in) {
+            HIP_TRY(hipMalloc((void **)&n_in, px * hl.nin * sizeof(float)));
+            HIP_TRY(w2xc_launch_repack(p_in, w, 1, (long long)px, n_in, (long long)w * hl.nin, hl.nin, 1, h, w, hl.nin, nullptr));
+            d.in = n_in; d.in_rs = (long long)w * hl.nin; d.in_ps = hl.nin; d.in_cs = 1;
+        } else {
+            d.in = p_in; d.in_rs = w; d.in_ps = 1; d.in_cs = (long long)px;
+        }
+        if (nhwc_out) {
+            HIP_TRY(hipMalloc((void **)&n_out, px * hl.nout * sizeof(float)));
+            d.out = n_out; d.out_rs = (long long)w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
+        } else {
+            d.out = p_out; d.out_rs = w; d.out_ps = 1; d.out_cs = (long long)px;
+        }
+        int r = launch_layer(c, m, layer, kind, d, nullptr, false);
+        if (r) return r;
+        if (nhwc_out)
+            HIP_TRY(w2xc_launch_repack(n_out, (long long)w * hl.nout, hl.nout, 1, p_out, w, 1, (long long)px, h, w, hl.nout, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        for (int oo = 0; oo < hl.nout; oo++)
+            HIP_TRY(hipMemcpy2D(out_planes[oo], out_stride_bytes, p_out + px * oo, (size_t)w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost));
+        return W2XC_OK;
+    };
+    rc = body();
+    cleanup();
+    return rc;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------
+int w2xc_profile_read(w2xc_model *m, int device, float *layer_ms, int *layer_launches, int n_layers)
+{
+    if (!m) return fail(W2XC_ERR_ARG, "null model");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    DevCtx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        auto it = m->ctx.find(device);
+        if (it == m->ctx.end()) return fail(W2XC_ERR_ARG, "no context for device %d", device);
+        c = it->second.get();
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(device);
+    for (auto &e : c->pending) {
+        HIP_TRY(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        c->layer_ms[e.layer] += ms;
+        c->layer_launches[e.layer] += 1;
+        c->pool.push_back(e);
+    }
+    c->pending.clear();
+    for (int l = 0; l < n_layers && l < (int)c->layer_ms.size(); l++) {
+        if (layer_ms) layer_ms[l] = (float)c->layer_ms[l];
+        if (layer_launches) layer_launches[l] = c->layer_launches[l];
+    }
+    return W2XC_OK;
+}
+
+void w2xc_profile_reset(w2xc_model *m, int device)
+{
+    if (!m) return;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(m->mu);
+    auto it = m->ctx.find(device);
+    if (it == m->ctx.end()) return;
+    DevCtx *c = it->second.get();
+    std::lock_guard<std::mutex> lk2(c->mu);
+    for (auto &e : c->pending) c->pool.push_back(e);
+    c->pending.clear();
+    std::fill(c->layer_ms.begin(), c->layer_ms.end(), 0.0);
+    std::fill(c->layer_launches.begin(), c->layer_launches.end(), 0);
+}
+
+const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_opts *opts)
+{
+    if (!m || layer < 0 || layer >= (int)m->layers.size()) return "";
+    const w2xc_opts o = resolve_opts(opts);
+    return w2xc_kernel_name(layer_kind(m, layer, o), m->layers[layer].nin, m->layers[layer].nout);
+}
+
+}  // extern "C"

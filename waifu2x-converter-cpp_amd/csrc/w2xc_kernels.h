@@ -1,0 +1,48 @@
+// w2xc_kernels.h -- launch interface between the engine (w2xc_engine.cpp) and the gfx950
+// kernels (w2xc_kernels.hip).  One "layer launch" computes
+//     out(y,x,o) = leaky( bias[o] + sum_{i,r,c} W[o][i][r][c] * in(clamp(y+r+off_y), clamp(x+c+off_x), i) )
+// which is Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159) on one haloed
+// band: off = 0 gives the shrinking "valid" conv used inside convertWithModels,
+// off = -1 with out dims == in dims gives the same-size BORDER_REPLICATE conv of Model::filter,
+// off = -n_layers on layer 1 folds cv::copyMakeBorder (convertRoutine.cpp:35,96) into the load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct W2xcConvDesc {
+    const float *in;
+    float *out;
+    const float *wpk;    // weights packed for the chosen kernel
+    const float *bias;   // float[cout]  ((float)double, modelHandler.cpp:147 via cv::add scalar rule)
+    int cin, cout;
+    // element (y,x,c) lives at base[y*rs + x*ps + c*cs] (units: floats)
+    long long in_rs, in_ps, in_cs;
+    long long out_rs, out_ps, out_cs;
+    int in_h, in_w;      // extent of the input view (clamp bounds)
+    int out_h, out_w;    // region to compute
+    int off_y, off_x;
+};
+
+enum W2xcKernelKind {
+    W2XC_K_DIRECT = 0,   // any shape, any strides, reference summation order (VALU)
+    W2XC_K_MFMA = 1,     // cin, cout in {32,64,128}; NHWC in/out; fp32 MFMA implicit GEMM
+    W2XC_K_FIRST = 2,    // cin <= 3 -> cout multiple of 32: planar in, NHWC out, fp32 MFMA (K = 9*cin)
+    W2XC_K_LAST = 3,     // cin multiple of 32 -> cout <= 3: NHWC in, planar out, taps-as-N fp32 MFMA
+};
+
+// Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
+W2xcKernelKind w2xc_pick_kernel(int cin, int cout);
+const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout);
+
+// Size in floats of the packed weight image for `kind`, and the packer (host side).
+// w is [cout][cin][3][3] (index o*cin+i, modelHandler.cpp:102).
+size_t w2xc_packed_weight_floats(W2xcKernelKind kind, int cin, int cout);
+void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, float *dst);
+
+// Enqueue one layer on `stream`.  Returns hipSuccess or the launch error.
+hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream);
+
+// strided element copy (planar <-> NHWC repack at the Model::filter boundary)
+hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, long long s_cs,
+                              float *dst, long long d_rs, long long d_ps, long long d_cs,
+                              int h, int w, int c, hipStream_t stream);
