@@ -136,20 +136,41 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
     const float *a_lane = lds + ((wm * MB) * HW + (lane & 31)) * CS + (lane >> 5) * 4;
     const f32x4 *b_lane = reinterpret_cast<const f32x4 *>(d.wpk) + (wn * NB) * 64 + lane;
 
+    // ---- halo-slice staging, split in two (issue early / write late): the global loads of slice
+    //      c+1 are issued before the MFMA loop of slice c and land in registers while the matrix
+    //      cores work; after the loop they are written to LDS between two barriers.  8 lanes move
+    //      one pixel's 128 B.  Offsets are in float4 units (16 B) so 32 bits cover 64 GiB. ----
+    constexpr int Q = CC / 4;
+    constexpr int NFILL = HH * HW * Q;
+    constexpr int PF = (NFILL + NT - 1) / NT;
+    unsigned goff[PF];
+    f32x4 pf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+        int idx = threadIdx.x + u * NT;
+        idx = idx < NFILL ? idx : NFILL - 1;
+        const int p = idx / Q, q = idx - p * Q;
+        const int py = p / HW, px = p - py * HW;
+        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
+        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
+        goff[u] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 2) + q;
+    }
+    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
+#pragma unroll
+    for (int u = 0; u < PF; u++) pf[u] = in4[goff[u]];
+
     for (int c0 = 0; c0 < CIN; c0 += CC) {
-        if (c0) __syncthreads();
-        // ---- stage the (HH x HW) x CC halo slice: 8 lanes move one pixel's 128 B ----
-        constexpr int Q = CC / 4;
-        for (int idx = threadIdx.x; idx < HH * HW * Q; idx += NT) {
-            const int p = idx / Q, q = idx - p * Q;
-            const int py = p / HW, px = p - py * HW;
-            const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
-            const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(d.in + (long long)gy * d.in_rs +
-                                                             (long long)gx * CIN + c0 + q * 4);
-            *reinterpret_cast<f32x4 *>(lds + p * CS + q * 4) = v;
+        if (c0) __syncthreads();   // every wave is done reading the previous slice
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int idx = threadIdx.x + u * NT;
+            if (idx < NFILL) *reinterpret_cast<f32x4 *>(lds + (idx / Q) * CS + (idx % Q) * 4) = pf[u];
         }
         __syncthreads();
+        if (c0 + CC < CIN) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = in4[goff[u] + (c0 + CC) / 4];
+        }
 
         const f32x4 *bp = b_lane + (long long)(c0 / 8) * NBT * 64;
         f32x4 a_cur[MB], b_cur[NB];
