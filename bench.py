@@ -55,35 +55,65 @@ def synth_frame_luma(seed, h=1080, w=1920):
 
 
 def cpu_baseline(layers, plane, budget_s=15.0):
-    """Time the CPU oracle ("port": restatement of the reference algorithm, oracle/w2xc_oracle.c) on whole
-    512x512 blocks of the same plane, nJob = host cores.  Returns the cpu_baseline object."""
+    """Time the CPU oracle ("port": restatement of the reference algorithm, oracle/w2xc_oracle.c -- the
+    real binary needs OpenCV, which is absent) on whole 512x512 blocks of the same plane.
+
+    Threads: the reference partitions OUTPUT PLANES over nJob std::threads with floor(nOut/nJob) each
+    and the remainder on the last thread (modelHandler.cpp:42-65).  With nJob > nOut every plane lands
+    on the last thread, so on this topology (nOut = 32/32/64/64/128/128/1) nJob = 32 is the largest job
+    count that still spreads every conv layer evenly; nJob = nproc on a 256-core host would serialise
+    the 32- and 64-plane layers.  We therefore time nJob = min(32, cores) as the baseline (cores =
+    threads actually busy) and, for context, the reference's default nJob = 4 (main.cpp:58-60)."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    njob = max(1, min(32, ncpu))
     o = orc.Oracle(layers)
-    blk = np.ascontiguousarray(plane[:498, :498])   # pads to one full 512x512 block (498 + 2*7)
-    t0 = time.perf_counter()
-    o.convert(blk, block_splitting=False, njob=cores)
-    t1 = time.perf_counter() - t0
-    n = 1
-    total = t1
-    while total + t1 <= budget_s and n < 8:
-        y0 = (n * 498) % (plane.shape[0] - 498)
-        blk = np.ascontiguousarray(plane[y0:y0 + 498, 498:996])
+
+    def one_block(idx, nj):
+        y0 = (idx * 498) % max(plane.shape[0] - 498, 1)
+        x0 = ((idx * 7) % 5) * 498 % max(plane.shape[1] - 498, 1)
+        blk = np.ascontiguousarray(plane[y0:y0 + 498, x0:x0 + 498])   # pads to one full 512x512 block
         t0 = time.perf_counter()
-        o.convert(blk, block_splitting=False, njob=cores)
-        total += time.perf_counter() - t0
+        o.convert(blk, block_splitting=False, njob=nj)
+        return time.perf_counter() - t0
+
+    t1 = one_block(0, njob)
+    n, total = 1, t1
+    while total + t1 <= budget_s * 0.75 and n < 8:
+        total += one_block(n, njob)
         n += 1
-    cnn_px = n * 498 * 498
-    return {
-        "value": round(cnn_px / 4.0 / total / 1e6, 6),
+    t4 = one_block(n, 4) if total + 8 * t1 <= budget_s * 2 else None
+    px_per_block = 498 * 498 / 4.0   # input-image pixels of one block (the CNN plane is the 2x image)
+    res = {
+        "value": round(n * px_per_block / total / 1e6, 6),
         "unit": "Mpix/s (input-image pixels)",
-        "cores": cores,
+        "cores": njob,
+        "host_cores": ncpu,
         "kind": "port",
-        "sample": "%d whole 512x512 blocks (498x498 useful CNN pixels each) of the same plane, nJob=%d std::thread-style "
-                  "output-plane partition, %.1f s; extrapolates to the plane because the reference's block-split "
-                  "path costs the same per block" % (n, cores, total),
+        "sample": "%d whole 512x512 blocks (498x498 useful CNN pixels each) of the same plane in %.1f s, nJob=%d "
+                  "(reference output-plane thread partition; the block-split path costs the same per block, so "
+                  "this extrapolates to the plane)" % (n, total, njob),
         "label": "CPU restatement of reference algorithm (OpenCV unavailable)",
     }
+    if t4 is not None:
+        res["value_njob4_reference_default"] = round(px_per_block / t4 / 1e6, 6)
+    return res
+
+
+def pmc_traffic(kernel, cin, cout, H, W):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_roofline.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).
+    rocprofv3 cannot run inside this process, so this is the profile of the SAME command
+    (tools/profile.sh); null when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r1_roofline.json")
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None
+    for name, k in prof.get("kernels", {}).items():
+        if kernel in name and ("<%d, %d" % (cin, cout)) in name and k.get("pixels") == (H + 2) * (W + 2):
+            return int(k["hbm_traffic_bytes"])
+    return None
 
 
 def main():
@@ -195,7 +225,10 @@ def main():
                        "sharding": "independent frames per rank, no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom), dom + 1) + ms.planes(dom)),
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
+                         if dom == n_layers - 2 else None,
+                         "algorithmic_bytes": (ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * (H + 2 * (n_layers - dom - 1)) * (W + 2 * (n_layers - dom - 1)),
                          "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops},
             "layers": per_layer,
             "output_finite": ok,

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Time ONE mid layer (cin->cout) on the GPU: model 1->cin->cout->1, per-layer hipEvent times.
+   W2XC_MFMA_VARIANT=<n> python tools/layer_bench.py --cin 128 --cout 128"""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as graft
+from oracle import gen_model
+ap = argparse.ArgumentParser()
+ap.add_argument("--cin", type=int, default=128); ap.add_argument("--cout", type=int, default=128)
+ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+w2xc = graft.load_package()
+ms = w2xc._ModelSet.from_layers(gen_model.synth_layers([1, a.cin, a.cout, 1], 7))
+x = torch.rand(a.h, a.w, device="cuda"); y = torch.empty_like(x)
+o = w2xc.make_opts(device=0, profile=1)
+st = torch.cuda.current_stream()
+for i in range(a.steps + 1):
+    if i == 1: torch.cuda.synchronize(); ms.profile_reset(0)
+    ms.convert_device(x.data_ptr(), a.w * 4, a.w, a.h, y.data_ptr(), a.w * 4, stream=st.cuda_stream, opts=o)
+torch.cuda.synchronize()
+t, n = ms.profile_read(0)
+t2 = t[1] / n[1]
+flops = 18.0 * a.cin * a.cout * (a.h + 2) * (a.w + 2)
+print("variant=%s %d->%d %dx%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (os.environ.get("W2XC_MFMA_VARIANT", "0"), a.cin, a.cout, a.h, a.w, t2, flops / t2 / 1e9, flops / t2 / 1e9 / 1.573))
