@@ -106,6 +106,15 @@ int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride
                               float *d_out, size_t out_stride_bytes, void *hip_stream,
                               const w2xc_opts *opts);
 
+/* Row-band form for sharding ONE plane over several processes / GPUs (the reference's block walk,
+ * convertRoutine.cpp:114-165, made parallel): computes output rows [row_begin, row_end) of the
+ * plane_h x w conversion.  `d_view` holds plane rows [view_y0, view_y0 + view_h) and must cover
+ * [row_begin - n_layers, row_end + n_layers) clipped to the plane; `d_out` points at output row
+ * row_begin.  Device pointers, asynchronous on `hip_stream`, no exchange between bands. */
+int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_stride_bytes, int view_h,
+                             int view_y0, int w, int plane_h, int row_begin, int row_end, float *d_out,
+                             size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);
+
 /* == Model::filter(inputPlanes, outputPlanes) for layer `layer` (modelHandler.cpp:26-72):
  * n_in_planes host planes of h x w floats in, nout planes out, SAME size, per-layer
  * BORDER_REPLICATE (:141-142), bias, LeakyReLU(0.1) (:147-152).  Returns W2XC_ERR_PLANES when

@@ -75,6 +75,7 @@ def _load():
         "w2xc_get_block_size": (None, [C.POINTER(ci), C.POINTER(ci)]),
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
+        "w2xc_convert_rows_device": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_layer_filter": (ci, [vp, ci, ci, C.POINTER(fp), cs, ci, ci, C.POINTER(fp), cs, C.POINTER(Opts)]),
         "w2xc_profile_read": (ci, [vp, ci, C.POINTER(C.c_float), C.POINTER(ci), ci]),
         "w2xc_profile_reset": (None, [vp, ci]),
@@ -230,6 +231,15 @@ class _ModelSet:
         if rc != OK:
             raise W2xcError(rc, last_error())
 
+    def convert_rows_device(self, d_view, view_stride_bytes, view_h, view_y0, w, plane_h, row_begin, row_end,
+                            d_out, out_stride_bytes, stream=0, opts=None):
+        """Row-band form (one shard of a plane): see w2xc_convert_rows_device in include/w2xc_hip.h."""
+        rc = _lib.w2xc_convert_rows_device(self.handle, C.c_void_p(d_view), view_stride_bytes, view_h, view_y0, w,
+                                           plane_h, row_begin, row_end, C.c_void_p(d_out), out_stride_bytes,
+                                           C.c_void_p(stream), C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+
     def filter(self, layer, planes, opts=None):
         """Model::filter: [nin,h,w] -> [nout,h,w]; raises W2xcError(ERR_PLANES) on a plane-count mismatch."""
         planes = [Mat(p).array for p in planes]
@@ -359,3 +369,16 @@ def convertWithModels(inputPlane, outputPlane, models, blockSplitting=True, opts
         return False
     Mat(res).copyTo(outputPlane)
     return True
+
+
+# ---- sharding one plane into independent row bands (multi-GPU: no exchange, host-side gather) ----
+def shard_rows(plane_h, n_parts, part):
+    """Output rows [begin, end) of shard `part` of `n_parts` (contiguous, sizes differ by <= 1 row).
+    Same split as the in-process multi-device path of w2xc_convert_plane (csrc/w2xc_engine.cpp)."""
+    return (plane_h * part) // n_parts, (plane_h * (part + 1)) // n_parts
+
+
+def shard_view(plane_h, row_begin, row_end, n_layers):
+    """Input rows [y0, y1) a shard needs: its rows plus an n_layers halo, clipped to the plane
+    (the 2*nModel overlap of the reference's block split, convertRoutine.cpp:100-131)."""
+    return max(0, row_begin - n_layers), min(plane_h, row_end + n_layers)

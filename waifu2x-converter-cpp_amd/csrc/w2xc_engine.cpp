@@ -507,6 +507,34 @@ int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride
     return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o);
 }
 
+int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_stride_bytes, int view_h, int view_y0, int w,
+                             int plane_h, int row_begin, int row_end, float *d_out, size_t out_stride_bytes,
+                             void *hip_stream, const w2xc_opts *opts)
+{
+    int rc = check_plane_args(m, d_view, view_stride_bytes, w, view_h, d_out, out_stride_bytes);
+    if (rc) return rc;
+    const int n = (int)m->layers.size();
+    if (plane_h <= 0 || row_begin < 0 || row_end > plane_h || row_begin >= row_end)
+        return fail(W2XC_ERR_ARG, "bad row range [%d,%d) for a %d-row plane", row_begin, row_end, plane_h);
+    if (view_y0 < 0 || view_y0 + view_h > plane_h || view_y0 > std::max(0, row_begin - n) ||
+        view_y0 + view_h < std::min(plane_h, row_end + n))
+        return fail(W2XC_ERR_ARG, "view rows [%d,%d) do not cover [%d,%d) +- %d halo rows", view_y0, view_y0 + view_h,
+                    row_begin, row_end, n);
+    const w2xc_opts o = resolve_opts(opts);
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    // a view that starts/ends inside the plane has artificial edges, but every row within n of
+    // them lies outside [row_begin, row_end), so clamping there never reaches a kept output row
+    return run_rows(m, c, d_view, view_stride_bytes / 4, view_h, view_y0, w, row_begin, row_end, d_out,
+                    out_stride_bytes / 4, (hipStream_t)hip_stream, o);
+}
+
 int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
                        size_t out_stride_bytes, int block_splitting, const w2xc_opts *opts)
 {
