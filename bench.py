@@ -79,7 +79,7 @@ def cpu_baseline(layers, plane, budget_s=15.0):
 
     t1 = one_block(0, njob)
     n, total = 1, t1
-    while total + t1 <= budget_s * 0.75 and n < 8:
+    while total + t1 <= budget_s * 0.75 and n < 64:
         total += one_block(n, njob)
         n += 1
     t4 = one_block(n, 4) if total + 8 * t1 <= budget_s * 2 else None
@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
+    ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane"],
+                    help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
+                         "ranks (BASELINE.json configs[2] with --width 8192 --height 8192): strong scaling")
     args = ap.parse_args()
 
     import torch
@@ -154,15 +157,27 @@ def main():
     ms = w2xc._ModelSet.from_layers(layers)
     n_layers = ms.n_layers
 
-    plane = synth_frame_luma(seed=2 + rank, h=args.height, w=args.width)
+    sharded = args.workload == "plane"
+    plane = synth_frame_luma(seed=2 + (0 if sharded else rank), h=args.height, w=args.width)
     H, W = plane.shape
-    d_in = torch.from_numpy(plane).cuda()
-    d_out = torch.empty_like(d_in)
     stream = torch.cuda.current_stream()
     opts = w2xc.make_opts(device=local_rank, profile=1, band_rows=args.band_rows)
+    if sharded:
+        # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo) is resident in HBM
+        ra, rb = w2xc.shard_rows(H, world, rank)
+        y0, y1 = w2xc.shard_view(H, ra, rb, n_layers)
+        d_in = torch.from_numpy(np.ascontiguousarray(plane[y0:y1])).cuda()
+        d_out = torch.empty((rb - ra, W), dtype=torch.float32, device="cuda")
 
-    def step():
-        ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=opts)
+        def step():
+            ms.convert_rows_device(d_in.data_ptr(), W * 4, y1 - y0, y0, W, H, ra, rb, d_out.data_ptr(), W * 4,
+                                   stream=stream.cuda_stream, opts=opts)
+    else:
+        d_in = torch.from_numpy(plane).cuda()
+        d_out = torch.empty_like(d_in)
+
+        def step():
+            ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=opts)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -189,23 +204,27 @@ def main():
 
     if rank == 0:
         in_px = args.height * args.width
-        value = world * in_px * args.steps / elapsed / 1e6
-        # dominant kernel: the layer with the most FLOPs
-        flops_layer = []
+        value = (1 if sharded else world) * in_px * args.steps / elapsed / 1e6
+        # algorithmic FLOPs of one step per layer: every band launch of layer k computes
+        # (band rows + 2(n-k)) x (W + 2(n-k)) pixels (valid conv on the haloed band)
+        band_h = (rb - ra) if sharded else H
+        flops_layer, nbands = [], []
         for l in range(n_layers):
             cin, cout = ms.planes(l)
             k = l + 1
-            oh, ow = H + 2 * (n_layers - k), W + 2 * (n_layers - k)   # whole-plane band
-            flops_layer.append(2 * 9 * cin * cout * oh * ow)
-        dom = int(np.argmax(flops_layer))
+            nb = max(launches[l] // max(args.steps, 1), 1)
+            nbands.append(nb)
+            px = nb * (band_h / nb + 2 * (n_layers - k)) * (W + 2 * (n_layers - k))
+            flops_layer.append(2 * 9 * cin * cout * px)
+        dom = int(np.argmax(flops_layer))   # dominant kernel: the layer with the most FLOPs
         dom_launches = max(launches[dom], 1)
         dom_ms = layer_ms[dom] / dom_launches
-        bands = dom_launches // max(args.steps, 1)
-        dom_flops = flops_layer[dom] / max(bands, 1) if bands > 1 else flops_layer[dom]
+        bands = nbands[dom]
+        dom_flops = flops_layer[dom] / bands
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         per_layer = []
         for l in range(n_layers):
-            ms_l = layer_ms[l] / max(launches[l], 1) * max(launches[l] // max(args.steps, 1), 1)
+            ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
             cin, cout = ms.planes(l)
             per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l), "planes": "%d->%d" % (cin, cout),
                               "ms": round(ms_l, 4),
@@ -216,19 +235,19 @@ def main():
             "unit": "Mpix/s (input-image pixels; CNN-plane pixels = 4x)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "scale2x_1080p: scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
+            "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
                                    "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
                                    "planes resident in HBM" % (args.width, args.height, W, H),
-                       "cnn_plane": [H, W], "frames_per_step": world, "bands_per_frame": max(bands, 1),
+                       "cnn_plane": [H, W], "frames_per_step": 1 if sharded else world, "bands_per_frame": max(bands, 1),
                        "sharding": "independent frames per rank, no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom), dom + 1) + ms.planes(dom)),
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
-                         if dom == n_layers - 2 else None,
-                         "algorithmic_bytes": (ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * (H + 2 * (n_layers - dom - 1)) * (W + 2 * (n_layers - dom - 1)),
+                         if (dom == n_layers - 2 and bands == 1 and not sharded) else None,
+                         "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
                          "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops},
             "layers": per_layer,
             "output_finite": ok,

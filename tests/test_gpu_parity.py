@@ -198,6 +198,32 @@ def test_device_pointer_entry_point(gpu, scale_layers):
     assert launches == [1] * 7 and all(t > 0 for t in ms_t)
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_row_band_entry_point(gpu, scale_layers, parts):
+    """w2xc_convert_rows_device: shards of one plane are independent and stitch bit-exactly
+    (the multi-GPU decomposition, exercised here on one device)."""
+    torch = pytest.importorskip("torch")
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    h, w = 150, 90
+    x = rand_plane(h, w, 13)
+    whole = ms.convert(x)
+    out = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    o = gpu.make_opts(device=0)
+    for p in range(parts):
+        ra, rb = gpu.shard_rows(h, parts, p)
+        y0, y1 = gpu.shard_view(h, ra, rb, ms.n_layers)
+        view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
+        ms.convert_rows_device(view.data_ptr(), w * 4, y1 - y0, y0, w, h, ra, rb, out[ra:].data_ptr(), w * 4,
+                               stream=st.cuda_stream, opts=o)
+    st.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole)
+    with pytest.raises(gpu.W2xcError) as e:     # a view that lacks its halo rows is rejected
+        v = torch.zeros((10, w), device="cuda")
+        ms.convert_rows_device(v.data_ptr(), w * 4, 10, 50, w, h, 50, 60, out.data_ptr(), w * 4, opts=o)
+    assert e.value.code == gpu.ERR_ARG
+
+
 def test_wide_model_cfg5_boundary(gpu):
     """BASELINE.json configs[4] shape (3->128->...->3) goes through Model::filter (convertWithModels
     can only push one plane, convertRoutine.cpp:63-64)."""
