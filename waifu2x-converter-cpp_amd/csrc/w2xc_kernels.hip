@@ -25,6 +25,7 @@
 // fp32 MFMA on gfx950 is an exact k-ordered fmaf chain at the f32 vector rate (157.3 TF peak).
 #include "w2xc_kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -226,6 +227,294 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3_mfma2: second-generation fp32 MFMA implicit GEMM -- every MFMA operand comes from LDS and
+// every byte gets there by LDS-DMA (global_load_lds_dwordx4), so the matrix-core instruction stream
+// only ever waits on lgkmcnt; the in-order vmcnt queue holds nothing but bulk transfers issued two
+// or more stages ahead and the epilogue stores.
+//
+//   Persistent workgroup (1 per CU, 4 waves, one per SIMD, up to 512 registers each), tile = 8 rows
+//   x 32 pixels x COUT planes; wave (wm, wn) owns MB row-blocks x NB plane-blocks (MB*WM = 8).
+//   Stage = (32-channel slice, tap): 4 k-groups of 8 channels = 16*MB*NB MFMAs per wave.
+//   LDS:  A[2] x 44 KiB  halo tile (10 x 34 pixels x 32 channels) of the current / next slice,
+//                        UNPADDED 128 B per pixel, 16-byte chunk q of pixel p stored at chunk
+//                        position q ^ ((p>>1)&7)  (DMA writes are lane-linear, so the swizzle is
+//                        applied to the per-lane SOURCE address; ds_read_b128 of 32 consecutive
+//                        pixels is then conflict-free in all four 16-lane groups)
+//         B[4] x 4*NBT KiB  the weights of one stage in MFMA fragment order (a straight copy of
+//                        wpk[tap][4 k-groups][NBT][64 lanes][4]); ring of 4 stages.
+//   Schedule at stage t:  issue DMA B(t+3) and up to 2 pieces of A(next slice | next tile);
+//   at its end wait (counted vmcnt) for this wave's share of B(t+2) [and A(next) when t = 7],
+//   raw s_barrier.  B(t+1) was already complete at the previous barrier, so the first fragments
+//   of stage t+1 are read BEFORE the barrier and the MFMA stream runs across it.
+// ------------------------------------------------------------------------------------------------
+// m0 carries the wave-uniform LDS byte address of the transfer; it is compiler-reserved and this
+// kernel uses it for nothing else, so it is simply overwritten (clobber listed: hipcc only warns).
+static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(gptr), "s"(lds_byte_addr)
+                 : "memory", "m0");
+}
+// scalar base + 32-bit per-lane byte offset + immediate: no 64-bit VALU address per transfer
+template <int IMM>
+static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
+                 : "memory", "m0");
+}
+#ifndef V2_PIN_READS
+#define V2_PIN_READS 0
+#endif
+#define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
+{
+    constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
+    constexpr int NSL = CIN / 32, NBT = COUT / 32;
+    constexpr int APW = 11;                          // A pieces (1 KiB) per wave per slice: 44 >= 42.5
+    constexpr unsigned A_BYTES = 4 * APW * 1024;     // 45056
+    constexpr int BPW = NBT;                         // B pieces per wave per stage (4*NBT in total)
+    constexpr unsigned B_BYTES = 4 * NBT * 1024;
+    constexpr unsigned B_BASE = 2 * A_BYTES;
+    static_assert(WM * WN == 4 && MB * WM == ROWS && NB * WN == NBT, "tile shape");
+    static_assert(CIN % 32 == 0 && COUT % 32 == 0, "planes");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nb0 = wn * NB;
+    const int li = lane & 31, kk = lane >> 5;
+
+    // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the tile list
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
+    int tile = chunk_begin + (blockIdx.x >> 3);
+    if (tile >= chunk_end) return;
+
+    float bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) bv[nb] = d.bias[(nb0 + nb) * 32 + li];
+
+    // ---- per-lane DMA source offsets of the A halo tile (16-byte units), piece jj of this wave ----
+    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
+    unsigned goff[APW];
+    auto tile_offsets = [&](int t) {
+        const int ty_ = t / tiles_x, tx_ = t - ty_ * tiles_x;
+#pragma unroll
+        for (int jj = 0; jj < APW; jj++) {
+            const int s = (jj * 4 + wave) * 64 + lane;            // 16-byte slot in the A buffer
+            int p = s >> 3;
+            p = p < NPIX ? p : NPIX - 1;                           // slots past the tile re-read its last pixel
+            const int q = (s & 7) ^ ((p >> 1) & 7);                // chunk stored at this position
+            const int py = p / HW, px = p - py * HW;
+            const int gy = clampi(ty_ * ROWS + py + d.off_y, 0, d.in_h - 1);
+            const int gx = clampi(tx_ * 32 + px + d.off_x, 0, d.in_w - 1);
+            goff[jj] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 2) + q;
+        }
+    };
+    const unsigned b_voff = (unsigned)((wave * BPW) * 64 + lane) * 16u;                      // this wave's B pieces
+    auto dma_b = [&](int sl_, int tap_, unsigned buf, int jb) {   // piece jb of stage (sl_, tap_) -> ring slot buf
+        const char *sbase = reinterpret_cast<const char *>(d.wpk) + (size_t)(tap_ * (CIN / 8) + sl_ * 4) * NBT * 1024;
+        const unsigned dst = lds0 + B_BASE + buf * B_BYTES + (unsigned)(wave * BPW) * 1024u;
+        switch (jb) {
+        case 0: lds_dma16_s<0>(sbase, b_voff, dst); break;
+        // the instruction's immediate offset is applied to BOTH the global and the LDS address
+        case 1: lds_dma16_s<1024>(sbase, b_voff, dst); break;
+        case 2: lds_dma16_s<2048>(sbase, b_voff, dst); break;
+        default: lds_dma16_s<3072>(sbase, b_voff, dst); break;
+        }
+    };
+    auto dma_a = [&](unsigned add, unsigned abuf, int jj) {
+        lds_dma16(in4 + goff[jj] + add, lds0 + abuf * A_BYTES + (unsigned)(jj * 4 + wave) * 1024u);
+    };
+
+    // ---- fragment addressing ----
+    // A: lane (li, kk) reads chunk q = 2*c8 + kk of pixel p = (wm*MB + row)*34 + li + tx, row = mb + ty:
+    //    byte p*128 + ((q ^ ((p>>1)&7)) << 4) = a0[row][tx] ^ (c8 << 5)  with a0 the c8 = 0 address
+    //    (bits 0..6 of p*128 are zero and 2*c8 only touches chunk bits 1..2).  a0 is tile-independent.
+    unsigned a0[MB + 2][3];
+#pragma unroll
+    for (int row = 0; row < MB + 2; row++)
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++) {
+            const int p = (wm * MB + row) * HW + li + tx;
+            a0[row][tx] = (unsigned)(p * 128 + ((((p >> 1) & 7) ^ kk) << 4));
+        }
+    auto a_addr = [&](unsigned abuf, int mb, int tap, int c8) -> const f32x4 * {
+        return reinterpret_cast<const f32x4 *>(ldsb + ((a0[mb + tap / 3][tap % 3] ^ (unsigned)(c8 << 5)) + abuf * A_BYTES));
+    };
+    auto b_addr = [&](unsigned buf, int c8, int nb) -> const f32x4 * {
+        return reinterpret_cast<const f32x4 *>(ldsb + B_BASE + buf * B_BYTES + ((c8 * NBT + nb0 + nb) * 64 + lane) * 16);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+
+    // ---- prologue: A(slice 0) and B stages 0..2 of the first tile ----
+    tile_offsets(tile);
+#pragma unroll
+    for (int jj = 0; jj < APW; jj++) dma_a(0, 0, jj);
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int jb = 0; jb < BPW; jb++) dma_b((t / 9) % NSL, t % 9, t & 3, jb);
+    W2XC_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+
+    unsigned gs = 0;      // global stage counter (only gs & 3 matters): ring slot of the current stage
+    unsigned abuf = 0;    // A buffer of the current slice
+    int sl = 0;
+    f32x4 a_cur[MB], b_cur[NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) a_cur[mb] = *a_addr(0, mb, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) b_cur[nb] = *b_addr(0, 0, nb);
+
+    for (;;) {
+        // what the A pieces issued during this slice fetch: the next slice, or the next tile's first
+        const bool last_slice = (sl == NSL - 1);
+        unsigned a_add = (unsigned)(sl + 1) * 8;
+        if (last_slice) {
+            tile_offsets(tile + per < chunk_end ? tile + per : tile);
+            a_add = 0;
+        }
+        const int sl_next = last_slice ? 0 : sl + 1;
+
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            // stage (sl, tap) in ring slot gs&3; DMA targets: B of stage +3, A pieces 2 per stage on taps 0..5
+            const int tap3 = (tap + 3) % 9;
+            const int sl3 = (tap + 3 < 9) ? sl : sl_next;
+            const unsigned buf = gs & 3u, buf3 = (gs + 3u) & 3u, buf1 = (gs + 1u) & 3u;
+            constexpr int KA[9] = {2, 2, 2, 2, 2, 1, 0, 0, 0};
+            const int ja0 = tap * 2;   // first A piece of this stage (valid while tap < 6)
+#pragma unroll
+            for (int c8 = 0; c8 < 4; c8++) {
+                // One step = M MFMAs.  Every other instruction is pinned into an MFMA shadow:
+                //   the MB + NB fragment reads of the NEXT step (the last step of a stage reads the next
+                //   stage's first fragments, which the previous barrier already guaranteed), spaced evenly;
+                //   the DMAs: step 0: [A piece, A piece,] B piece 0; steps 1..3: B piece c8.
+                constexpr int M = 4 * MB * NB, R = MB + NB;
+                const bool wrap = (c8 == 3);
+                const int tap_n = wrap ? (tap + 1) % 9 : tap, c8_n = wrap ? 0 : c8 + 1;
+                const unsigned abuf_n = (wrap && tap == 8) ? (abuf ^ 1u) : abuf;
+                const unsigned bbuf_n = wrap ? buf1 : buf;
+                f32x4 a_nxt[MB], b_nxt[NB];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
+                            const int m = (j * MB + mb) * NB + nb;        // MFMA index in the step
+                            if (c8 == 0 && (m == 1 || m == 3) && (m >> 1) < KA[tap]) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (!(ABL & 4)) dma_a(a_add, abuf ^ 1u, ja0 + (m >> 1));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (m == (c8 == 0 ? 5 : 1) && c8 < BPW) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (!(ABL & 4)) dma_b(sl3, tap3, buf3, c8);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+                            for (int r = 0; r < R; r++) {
+                                if (m == 6 + (r * (M - 8)) / R) {         // reads spread over MFMAs 6 .. M-3
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (ABL & 8) { if (r < MB) a_nxt[r] = a_cur[r]; else b_nxt[r - MB] = b_cur[r - MB]; }
+                                    else if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
+                                    else b_nxt[r - MB] = *b_addr(bbuf_n, c8_n, r - MB);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) a_cur[mb] = a_nxt[mb];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) b_cur[nb] = b_nxt[nb];
+            }
+            // stage boundary.  The youngest transfer needed next is this wave's last piece of B(t+2),
+            // issued in stage t-1 after that stage's A pieces; the only younger transfers are the
+            // KA[t] + BPW issued in stage t (vmcnt retires in order; the epilogue stores of the
+            // previous tile, if any, are older than stage t's transfers and are retired too).
+            {
+                switch (KA[tap] + BPW) {
+                case 1: W2XC_WAIT_VMCNT(1); break;
+                case 2: W2XC_WAIT_VMCNT(2); break;
+                case 3: W2XC_WAIT_VMCNT(3); break;
+                case 4: W2XC_WAIT_VMCNT(4); break;
+                case 5: W2XC_WAIT_VMCNT(5); break;
+                default: W2XC_WAIT_VMCNT(6); break;
+                }
+                if (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            gs++;
+        }
+        abuf ^= 1u;
+
+        if (last_slice) {
+            // ---- epilogue: bias + LeakyReLU, NHWC stores (C/D: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)).
+            //      leaky(v) = max(v, 0.1f*v).  Interior tiles (all but the last row / column of tiles)
+            //      take the unpredicated path. ----
+            const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+            const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+            const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
+            float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
+            if (interior && !(ABL & 2)) {
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float v = acc[mb][nb][r] + bv[nb];
+                            obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                            acc[mb][nb][r] = 0.0f;
+                        }
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) {
+                    const int y = oy0 + wm * MB + mb;
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                            const float v = acc[mb][nb][r] + bv[nb];
+                            if ((ABL & 2) ? (x < -12345) : (y < d.out_h && x < d.out_w))
+                                obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                            acc[mb][nb][r] = 0.0f;
+                        }
+                }
+            }
+            tile += per;
+            if (tile >= chunk_end) break;
+            sl = 0;
+        } else {
+            sl++;
+        }
+    }
+    W2XC_WAIT_VMCNT(0);   // drain the speculative DMAs before the LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,6 +775,34 @@ static hipError_t launch_mfma(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int ABL = 0>
+static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+    const size_t lds_bytes = 2 * 45056 + 4 * (size_t)(4 * (COUT / 32) * 1024);
+    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
+    if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, d, tiles_x, ntiles);
+    return hipGetLastError();
+}
+
+// W2XC_MFMA_V2: unset = pick per shape (v2 everywhere except 32->32, where the v1 tiling measured
+// faster), 0 = force conv3x3_mfma (v1), 1 = force conv3x3_mfma2, >= 10 = ablation builds (tuning only)
+static int mfma_v2_enabled()
+{
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("W2XC_MFMA_V2"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
 template <typename KernelT>
 static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -501,6 +818,30 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
     if (kind == W2XC_K_MFMA) {
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
+        const int v2 = mfma_v2_enabled();
+        if (v2 > 0 || (v2 < 0 && key != 32032)) {
+            switch (key) {
+            //                            CIN  COUT  MB NB WM WN
+            case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
+            case 32064:  return launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
+            case 32128:  return launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
+            case 64032:  return launch_mfma2<64, 32, 2, 1, 4, 1>(d, stream);
+            case 64064:  return launch_mfma2<64, 64, 2, 2, 4, 1>(d, stream);
+            case 64128:  return launch_mfma2<64, 128, 4, 2, 2, 2>(d, stream);
+            case 128032: return launch_mfma2<128, 32, 2, 1, 4, 1>(d, stream);
+            case 128064: return launch_mfma2<128, 64, 2, 2, 4, 1>(d, stream);
+            case 128128:
+                switch (mfma_v2_enabled()) {
+                case 11: return launch_mfma2<128, 128, 4, 2, 2, 2, 1>(d, stream);    // ablations (wrong results)
+                case 12: return launch_mfma2<128, 128, 4, 2, 2, 2, 2>(d, stream);
+                case 14: return launch_mfma2<128, 128, 4, 2, 2, 2, 4>(d, stream);
+                case 18: return launch_mfma2<128, 128, 4, 2, 2, 2, 8>(d, stream);
+                case 25: return launch_mfma2<128, 128, 4, 2, 2, 2, 15>(d, stream);
+                default: return launch_mfma2<128, 128, 4, 2, 2, 2>(d, stream);
+                }
+            default: break;
+            }
+        }
         switch (key) {
         //                           CIN  COUT  MB NB WM WN
         case 32032:  return launch_mfma<32, 32, 2, 1, 4, 1>(d, stream);
