@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX>
+Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries:
+  PREFIX_kernel_stats.csv  (rocprofv3 --kernel-trace --stats)
+  PREFIX_pmc_summary.txt   (per-kernel means of every PMC counter)
+  PREFIX_roofline.json     (per-layer algorithmic FLOPs/bytes, HBM traffic, MFMA pipe utilisation)
+FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE reports 1/2 of wide streaming reads
+(MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024."""
+import csv, json, os, shutil, subprocess, sys
+base, prefix = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+H, W, NL = 2160, 3840, 7
+PLANES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)]
+shutil.copy(base + "trace/trace_kernel_stats.csv", prefix + "_kernel_stats.csv")
+here = os.path.dirname(os.path.abspath(__file__))
+pmcs = [base + d + "/pmc_counter_collection.csv" for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds")]
+open(prefix + "_pmc_summary.txt", "w").write(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py")] + pmcs, capture_output=True, text=True).stdout)
+
+def mean_counter(path, sub, counter):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if sub in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(v) / len(v) if v else None
+
+stats = {r["Name"]: r for r in csv.DictReader(open(base + "trace/trace_kernel_stats.csv"))}
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (tools/profile.sh)",
+       "note": __doc__.split("FETCH_SIZE", 1)[1].strip().replace("\n", " "), "kernels": {}}
+for k, (cin, cout) in enumerate(PLANES, 1):
+    sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d>" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
+    names = [n for n in stats if sub in n and n.startswith("void conv3x3")]
+    if not names:
+        continue
+    name = names[0]
+    px = (H + 2 * (NL - k)) * (W + 2 * (NL - k))
+    avg_ns = float(stats[name]["AverageNs"])
+    fetch = mean_counter(pmcs[0], sub, "FETCH_SIZE"); write = mean_counter(pmcs[1], sub, "WRITE_SIZE")
+    rd, wr = 2 * fetch * 1024, write * 1024
+    alg = (cin + cout) * 4 * px
+    e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px,
+         "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,
+         "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
+         "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}
+    grbm = mean_counter(pmcs[3], sub, "GRBM_GUI_ACTIVE"); busy = mean_counter(pmcs[2], sub, "SQ_VALU_MFMA_BUSY_CYCLES")
+    if grbm and busy:
+        e.update({"shader_clock_GHz": grbm / 8 / avg_ns, "mfma_pipe_utilisation": busy / (1024 * grbm / 8),
+                  "avg_waves_per_simd": mean_counter(pmcs[2], sub, "SQ_WAVE_CYCLES") * 4 / (grbm / 8) / 1024,
+                  "SQ_LDS_BANK_CONFLICT": mean_counter(pmcs[3], sub, "SQ_LDS_BANK_CONFLICT")})
+    out["kernels"][name] = e
+    print(k, name[:44], "%.2f ms %.1f TF  HBM %.2f GB (%.2fx alg)  mfma_util %.3f" % (avg_ns / 1e6, e["tflops"], (rd + wr) / 1e9, e["traffic_over_algorithmic"], e.get("mfma_pipe_utilisation", 0)))
+json.dump(out, open(prefix + "_roofline.json", "w"), indent=1)
