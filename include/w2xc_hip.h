@@ -115,6 +115,17 @@ int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_str
                              int view_y0, int w, int plane_h, int row_begin, int row_end, float *d_out,
                              size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);
 
+/* N1: the scale loop of the CLI -- cv::resize(INTER_NEAREST, 2x) of the luma plane
+ * (main.cpp:132-140) followed by convertWithModels (:148) -- as ONE call.  `in` is the h x w plane
+ * BEFORE the resize, `out` is 2h x 2w.  The nearest-neighbour upscale is folded into layer 1's load
+ * (source pixel (y>>1, x>>1)), so the 4x larger plane is never materialised nor copied over PCIe.
+ * Result == w2xc_convert_plane on the explicitly upscaled plane. */
+int w2xc_convert_plane_nn2x(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h,
+                            float *out, size_t out_stride_bytes, const w2xc_opts *opts);
+int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h,
+                                   float *d_out, size_t out_stride_bytes, void *hip_stream,
+                                   const w2xc_opts *opts);
+
 /* == Model::filter(inputPlanes, outputPlanes) for layer `layer` (modelHandler.cpp:26-72):
  * n_in_planes host planes of h x w floats in, nout planes out, SAME size, per-layer
  * BORDER_REPLICATE (:141-142), bias, LeakyReLU(0.1) (:147-152).  Returns W2XC_ERR_PLANES when

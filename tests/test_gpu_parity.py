@@ -224,6 +224,23 @@ def test_row_band_entry_point(gpu, scale_layers, parts):
     assert e.value.code == gpu.ERR_ARG
 
 
+@pytest.mark.parametrize("h,w", [(37, 53), (1, 1), (128, 160)])
+def test_nn2x_fused_into_layer1(gpu, scale_layers, h, w):
+    """N1: cv::resize(INTER_NEAREST, 2x) + convertWithModels (main.cpp:132-148) as one call equals
+    the conversion of the explicitly upscaled plane -- bit-exact on the GPU (same kernels downstream),
+    bit-exact against the oracle with the direct kernel, rtol 1e-4 with the MFMA kernels."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(h, w, 31 + h)
+    up = np.repeat(np.repeat(x, 2, axis=0), 2, axis=1)
+    want = orc.Oracle(scale_layers).convert(up)
+    fused = ms.convert_nn2x(x)
+    assert fused.shape == (2 * h, 2 * w)
+    assert np.array_equal(fused, ms.convert(up))
+    assert_close(fused, want, "nn2x %dx%d" % (h, w))
+    assert np.array_equal(ms.convert_nn2x(x, direct(gpu)), want)
+    assert np.array_equal(ms.convert_nn2x(x, gpu.make_opts(band_rows=16)), fused)   # banded: odd/even row origins
+
+
 def test_wide_model_cfg5_boundary(gpu):
     """BASELINE.json configs[4] shape (3->128->...->3) goes through Model::filter (convertWithModels
     can only push one plane, convertRoutine.cpp:63-64)."""

@@ -75,6 +75,8 @@ def _load():
         "w2xc_get_block_size": (None, [C.POINTER(ci), C.POINTER(ci)]),
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
+        "w2xc_convert_plane_nn2x": (ci, [vp, fp, cs, ci, ci, fp, cs, C.POINTER(Opts)]),
+        "w2xc_convert_plane_nn2x_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_rows_device": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_layer_filter": (ci, [vp, ci, ci, C.POINTER(fp), cs, ci, ci, C.POINTER(fp), cs, C.POINTER(Opts)]),
         "w2xc_profile_read": (ci, [vp, ci, C.POINTER(C.c_float), C.POINTER(ci), ci]),
@@ -222,6 +224,22 @@ class _ModelSet:
         if rc != OK:
             raise W2xcError(rc, last_error())
         return out
+
+    def convert_nn2x(self, plane, opts=None):
+        """cv::resize(INTER_NEAREST, 2x) + convertWithModels (main.cpp:132-148) in one call: h x w -> 2h x 2w."""
+        src = Mat(plane)
+        out = np.empty((2 * src.rows, 2 * src.cols), np.float32)
+        rc = _lib.w2xc_convert_plane_nn2x(self.handle, src.array.ctypes.data, src.step, src.cols, src.rows,
+                                          out.ctypes.data, out.strides[0], C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+        return out
+
+    def convert_nn2x_device(self, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, stream=0, opts=None):
+        rc = _lib.w2xc_convert_plane_nn2x_device(self.handle, C.c_void_p(d_in), in_stride_bytes, w, h, C.c_void_p(d_out),
+                                                 out_stride_bytes, C.c_void_p(stream), C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
 
     def convert_device(self, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, stream=0, opts=None):
         """Device-pointer form (ints: hipDeviceptr / hipStream_t).  Asynchronous on `stream`."""

@@ -238,8 +238,10 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
 
 // Output rows [ra, rb) of convertWithModels on an h-row plane of which `d_in` holds rows
 // [vy0, vy0+vh) -- every row in [ra-n, rb+n) clipped to the plane must be inside the view.
+// `up` = 1 folds a nearest-neighbour 2x (main.cpp:132-140) into layer 1: vh, vy0, w, ra, rb are then in
+// UPSCALED coordinates while d_in holds the (vh/2) x (w/2) source rows starting at source row vy0/2.
 int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,
-             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o)
+             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o, int up = 0)
 {
     const int n = (int)m->layers.size();
     if (n == 0) return fail(W2XC_ERR_ARG, "model has no layers");
@@ -303,6 +305,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.out_w = w + 2 * (n - k);
             d.off_y = k == 1 ? (y0 - n - vy0) : 0;
             d.off_x = k == 1 ? -n : 0;
+            d.in_shift = k == 1 ? up : 0;
             const bool direct_out = (k == n && hl.nout == 1);
             if (direct_out) {
                 d.out = d_out + (size_t)(y0 - ra) * out_stride_f;
@@ -535,12 +538,19 @@ int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_str
                     out_stride_bytes / 4, (hipStream_t)hip_stream, o);
 }
 
-int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
-                       size_t out_stride_bytes, int block_splitting, const w2xc_opts *opts)
+}  // extern "C"
+
+namespace {
+// host-pointer path shared by w2xc_convert_plane (up = 0) and w2xc_convert_plane_nn2x (up = 1).
+// (w, h) is the SOURCE plane; the output is (w << up) x (h << up).
+int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
+                       size_t out_stride_bytes, const w2xc_opts *opts, int up)
 {
-    (void)block_splitting;   // results do not depend on the reference's block split (SURVEY I2)
-    int rc = check_plane_args(m, in, in_stride_bytes, w, h, out, out_stride_bytes);
-    if (rc) return rc;
+    if (!m || !in || !out) return fail(W2XC_ERR_ARG, "null argument");
+    if (w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "plane size must be positive (got %dx%d)", w, h);
+    const int W = w << up, H = h << up;
+    if (in_stride_bytes < (size_t)w * 4 || out_stride_bytes < (size_t)W * 4 || (in_stride_bytes & 3) || (out_stride_bytes & 3))
+        return fail(W2XC_ERR_ARG, "row strides must be multiples of 4 bytes and >= 4*width");
     const w2xc_opts o = resolve_opts(opts);
     const int ndev_all = w2xc_device_count();
     if (ndev_all <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
@@ -550,34 +560,35 @@ int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     if (devs.empty()) return fail(W2XC_ERR_ARG, "device_mask 0x%x selects no available device (%d present)", o.device_mask, ndev_all);
     const int n = (int)m->layers.size();
     int nd = (int)devs.size();
-    if (nd > h) nd = h;
+    if (nd > H) nd = H;
 
     std::vector<int> rcs(nd, W2XC_OK);
     std::vector<std::string> errs(nd);
     auto worker = [&](int t) {
-        // contiguous row band [ra, rb) of the plane for device t: independent, no exchange
-        const int ra = (int)((long long)h * t / nd), rb = (int)((long long)h * (t + 1) / nd);
+        // contiguous band [ra, rb) of OUTPUT rows for device t: independent, no exchange
+        const int ra = (int)((long long)H * t / nd), rb = (int)((long long)H * (t + 1) / nd);
         auto body = [&]() -> int {
             HIP_TRY(hipSetDevice(devs[t]));
             DevCtx *c = nullptr;
             int r = get_ctx(m, devs[t], &c);
             if (r) return r;
-            const int vy0 = std::max(0, ra - n), vy1 = std::min(h, rb + n);
-            const int vh = vy1 - vy0;
+            // source rows that cover output rows [ra - n, rb + n) (clipped), in source coordinates
+            const int sy0 = std::max(0, ra - n) >> up, sy1 = (std::min(H, rb + n) + up) >> up;
+            const int svh = sy1 - sy0;
             float *d_in = nullptr, *d_out = nullptr;
             hipStream_t st = nullptr;
             HIP_TRY(hipStreamCreate(&st));
-            HIP_TRY(hipMalloc((void **)&d_in, (size_t)vh * w * sizeof(float)));
-            HIP_TRY(hipMalloc((void **)&d_out, (size_t)(rb - ra) * w * sizeof(float)));
-            HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)w * 4, (const char *)in + (size_t)vy0 * in_stride_bytes, in_stride_bytes,
-                                     (size_t)w * 4, vh, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMalloc((void **)&d_in, (size_t)svh * w * sizeof(float)));
+            HIP_TRY(hipMalloc((void **)&d_out, (size_t)(rb - ra) * W * sizeof(float)));
+            HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)w * 4, (const char *)in + (size_t)sy0 * in_stride_bytes, in_stride_bytes,
+                                     (size_t)w * 4, svh, hipMemcpyHostToDevice, st));
             {
                 std::lock_guard<std::mutex> lk(c->mu);
-                r = run_rows(m, c, d_in, w, vh, vy0, w, ra, rb, d_out, w, st, o);
+                r = run_rows(m, c, d_in, w, svh << up, sy0 << up, W, ra, rb, d_out, W, st, o, up);
             }
             if (r == W2XC_OK) {
-                HIP_TRY(hipMemcpy2DAsync((char *)out + (size_t)ra * out_stride_bytes, out_stride_bytes, d_out, (size_t)w * 4,
-                                         (size_t)w * 4, rb - ra, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpy2DAsync((char *)out + (size_t)ra * out_stride_bytes, out_stride_bytes, d_out, (size_t)W * 4,
+                                         (size_t)W * 4, rb - ra, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
             } else {
                 hipStreamSynchronize(st);
@@ -604,6 +615,46 @@ int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         if (rcs[t]) { g_last_error = errs[t]; std::cerr << errs[t] << std::endl; return rcs[t]; }
     return W2XC_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
+                       size_t out_stride_bytes, int block_splitting, const w2xc_opts *opts)
+{
+    (void)block_splitting;   // results do not depend on the reference's block split (SURVEY I2)
+    return convert_plane_host(m, in, in_stride_bytes, w, h, out, out_stride_bytes, opts, 0);
+}
+
+int w2xc_convert_plane_nn2x(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h, float *out,
+                            size_t out_stride_bytes, const w2xc_opts *opts)
+{
+    return convert_plane_host(m, in, in_stride_bytes, w, h, out, out_stride_bytes, opts, 1);
+}
+
+int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h, float *d_out,
+                                   size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts)
+{
+    if (!m || !d_in || !d_out) return fail(W2XC_ERR_ARG, "null argument");
+    if (w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "plane size must be positive (got %dx%d)", w, h);
+    if (in_stride_bytes < (size_t)w * 4 || out_stride_bytes < (size_t)w * 8 || (in_stride_bytes & 3) || (out_stride_bytes & 3))
+        return fail(W2XC_ERR_ARG, "row strides must be multiples of 4 bytes and >= 4*width");
+    const w2xc_opts o = resolve_opts(opts);
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    int rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run_rows(m, c, d_in, in_stride_bytes / 4, 2 * h, 0, 2 * w, 0, 2 * h, d_out, out_stride_bytes / 4,
+                    (hipStream_t)hip_stream, o, 1);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *const *in_planes, size_t in_stride_bytes,
                       int w, int h, float *const *out_planes, size_t out_stride_bytes, const w2xc_opts *opts)

@@ -21,6 +21,10 @@ struct W2xcConvDesc {
     int in_h, in_w;      // extent of the input view (clamp bounds)
     int out_h, out_w;    // region to compute
     int off_y, off_x;
+    // N1 (nearest-neighbour 2x of main.cpp:132-140 folded into the load): in_h/in_w and all offsets are
+    // in UPSCALED coordinates, memory is addressed at (y >> in_shift, x >> in_shift).  0 or 1; only the
+    // first-layer kernels (conv3x3_first, conv3x3_direct) honour it.
+    int in_shift;
 };
 
 enum W2xcKernelKind {

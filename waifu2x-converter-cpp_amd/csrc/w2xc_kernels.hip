@@ -59,9 +59,9 @@ __global__ void __launch_bounds__(256) conv3x3_direct(W2xcConvDesc d, int cout_p
     if (x >= d.out_w || y >= d.out_h) return;
     long long roff[3], coff[3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) roff[r] = (long long)clampi(y + r + d.off_y, 0, d.in_h - 1) * d.in_rs;
+    for (int r = 0; r < 3; r++) roff[r] = (long long)(clampi(y + r + d.off_y, 0, d.in_h - 1) >> d.in_shift) * d.in_rs;
 #pragma unroll
-    for (int c = 0; c < 3; c++) coff[c] = (long long)clampi(x + c + d.off_x, 0, d.in_w - 1) * d.in_ps;
+    for (int c = 0; c < 3; c++) coff[c] = (long long)(clampi(x + c + d.off_x, 0, d.in_w - 1) >> d.in_shift) * d.in_ps;
     float acc[DIRECT_CG];
 #pragma unroll
     for (int k = 0; k < DIRECT_CG; k++) acc[k] = 0.0f;                                  // :131-132
@@ -540,8 +540,8 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     for (int idx = threadIdx.x; idx < CIN * HH * HW; idx += 256) {
         const int c = idx / (HH * HW), p = idx - c * (HH * HW);
         const int py = p / HW, px = p - py * HW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);      // copyMakeBorder REPLICATE
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
+        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;      // copyMakeBorder REPLICATE
+        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;      // (+ INTER_NEAREST 2x when in_shift = 1)
         lds[idx] = d.in[(long long)c * d.in_cs + (long long)gy * d.in_rs + (long long)gx * d.in_ps];
     }
     __syncthreads();
@@ -815,6 +815,7 @@ static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.in_shift != 0 && kind != W2XC_K_FIRST && kind != W2XC_K_DIRECT) return hipErrorInvalidValue;
     if (kind == W2XC_K_MFMA) {
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
