@@ -144,13 +144,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # one rank per GPU; (ranks share a GPU only in the gloo self-test)
+    torch.cuda.set_device(dev_index)
     dist = None
+    backend = os.environ.get("W2XC_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" for the 1-GPU self-test
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     w2xc = graft.load_package()
     layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
@@ -161,7 +168,7 @@ def main():
     plane = synth_frame_luma(seed=2 + (0 if sharded else rank), h=args.height, w=args.width)
     H, W = plane.shape
     stream = torch.cuda.current_stream()
-    opts = w2xc.make_opts(device=local_rank, profile=1, band_rows=args.band_rows)
+    opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows)
     if sharded:
         # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo) is resident in HBM
         ra, rb = w2xc.shard_rows(H, world, rank)
@@ -188,18 +195,18 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    ms.profile_reset(local_rank)
+    ms.profile_reset(dev_index)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    layer_ms, launches = ms.profile_read(local_rank)
+    layer_ms, launches = ms.profile_read(dev_index)
     ok = bool(torch.isfinite(d_out).all().item())
 
     if rank == 0:
@@ -252,7 +259,7 @@ def main():
             "layers": per_layer,
             "output_finite": ok,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(layers, plane, args.cpu_budget)
             out["speedup_vs_cpu"] = round(value / world / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))

@@ -280,3 +280,24 @@ def test_full_size_patches_and_band_invariance(gpu, scale_layers):
         assert_close(got[y:y + ph, x:x + pw], want, "patch (%d,%d)" % (y, x))
     banded = ms.convert(plane, opts=gpu.make_opts(band_rows=500))
     assert np.array_equal(got, banded)
+
+
+def test_large_plane_beyond_4gib_buffers(gpu, scale_layers):
+    """maximum sizes: a 3000 x 9000 plane in ONE band makes the 128-plane activation buffers 13.9 GB each,
+    so every kernel addresses well past 2^32 bytes; patches at the far end (highest addresses), at a band
+    seam of a second, banded run and at the borders are checked against the oracle."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    H, W = 3000, 9000
+    rng = np.random.default_rng(77)
+    plane = rng.random((H, W), dtype=np.float32)
+    got = ms.convert(plane, opts=gpu.make_opts(workspace_mb=40000))
+    assert np.isfinite(got).all()
+    o = orc.Oracle(scale_layers)
+    for (y, x) in [(H - 40, W - 40), (H - 40, 0), (0, W - 40), (1499, 4500), (2990, 8000), (2000, 8960)]:
+        ph = pw = 32
+        y, x = min(y, H - ph), min(x, W - pw)
+        y0, y1, x0, x1 = max(0, y - 7), min(H, y + ph + 7), max(0, x - 7), min(W, x + pw + 7)
+        sub = o.convert(np.ascontiguousarray(plane[y0:y1, x0:x1]), block_splitting=False, njob=8)
+        assert_close(got[y:y + ph, x:x + pw], sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw], "patch (%d,%d)" % (y, x))
+    banded = ms.convert(plane, opts=gpu.make_opts(workspace_mb=6000))
+    assert np.array_equal(got, banded)
