@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic; NOT the headline number: the reference "
+                         "computes in fp32 and `value` is only valid for the default)")
     ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane"],
                     help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
                          "ranks (BASELINE.json configs[2] with --width 8192 --height 8192): strong scaling")
@@ -168,7 +171,8 @@ def main():
     plane = synth_frame_luma(seed=2 + (0 if sharded else rank), h=args.height, w=args.width)
     H, W = plane.shape
     stream = torch.cuda.current_stream()
-    opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows)
+    opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows,
+                          precision=w2xc.PRECISION_BF16 if args.precision == "bf16" else w2xc.PRECISION_FP32)
     if sharded:
         # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo) is resident in HBM
         ra, rb = w2xc.shard_rows(H, world, rank)
@@ -233,7 +237,7 @@ def main():
         for l in range(n_layers):
             ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
             cin, cout = ms.planes(l)
-            per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l), "planes": "%d->%d" % (cin, cout),
+            per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l, opts), "planes": "%d->%d" % (cin, cout),
                               "ms": round(ms_l, 4),
                               "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None})
         out = {
@@ -243,17 +247,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 activations/weights between layers, f32 accumulate (not the headline precision)",
+            "data": "synthetic",
             "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
                                    "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
                                    "planes resident in HBM" % (args.width, args.height, W, H),
                        "cnn_plane": [H, W], "frames_per_step": 1 if sharded else world, "bands_per_frame": max(bands, 1),
                        "sharding": "independent frames per rank, no collective on the data path"},
-            "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom), dom + 1) + ms.planes(dom)),
-                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom, opts), dom + 1) + ms.planes(dom)),
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else 2500.0, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else 2500.0), 4),
                          "traffic": pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
-                         if (dom == n_layers - 2 and bands == 1 and not sharded) else None,
+                         if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else None,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
                          "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops},
             "layers": per_layer,

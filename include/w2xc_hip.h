@@ -37,7 +37,10 @@ extern "C" {
 typedef struct w2xc_model w2xc_model;
 
 #define W2XC_PRECISION_FP32 0   /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-f32 fma chains        */
-#define W2XC_PRECISION_BF16 1   /* bf16 operands, fp32 accumulate (reserved)        */
+#define W2XC_PRECISION_BF16 1   /* w2xc_convert_* only: activations BETWEEN layers are bf16 (RNE), layers
+                                 * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
+                                 * accumulate, bias and LeakyReLU; first / last layer arithmetic stays
+                                 * fp32.  Not the reference's arithmetic: tolerance in DESIGN.md 4.  */
 
 #define W2XC_KERNEL_AUTO    0   /* MFMA implicit-GEMM where the layer shape allows                 */
 #define W2XC_KERNEL_DIRECT  1   /* reference-ordered direct conv on VALU (bit-exact vs the oracle) */

@@ -301,3 +301,57 @@ def test_large_plane_beyond_4gib_buffers(gpu, scale_layers):
         assert_close(got[y:y + ph, x:x + pw], sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw], "patch (%d,%d)" % (y, x))
     banded = ms.convert(plane, opts=gpu.make_opts(workspace_mb=6000))
     assert np.array_equal(got, banded)
+
+
+# ---- W2XC_PRECISION_BF16 (BASELINE.json configs[3]) ------------------------------------------------
+def psnr(a, b, peak=1.0):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 10 * np.log10(peak * peak / max(mse, 1e-30))
+
+
+@pytest.mark.parametrize("planes", [[1, 32, 1], [1, 32, 32, 1], [1, 64, 128, 1], [1, 128, 64, 32, 1], [1, 32, 32, 64, 64, 128, 128, 1]])
+@pytest.mark.parametrize("h,w", [(45, 77), (8, 32)])
+def test_bf16_path_matches_its_emulation(gpu, planes, h, w):
+    """bf16 activations between layers, bf16 weights in the middle layers, fp32 accumulate: checked
+    against a float64-accumulate emulation of the same dataflow.  Tolerance: 1e-2 of the output range
+    (one bf16 ulp of a mid-layer activation is 2^-8 relative; accumulation-order differences can flip
+    individual roundings), plus a tight mean-error bound that a layout bug could not meet."""
+    import bf16_ref
+    layers = small_layers(planes, 400 + len(planes))
+    ms = gpu._ModelSet.from_layers(layers)
+    x = rand_plane(h, w, 5 + h)
+    got = ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16))
+    want = bf16_ref.convert_bf16_emulated(layers, x)
+    scale = float(np.abs(want).max())
+    assert np.abs(got - want).max() <= 1e-2 * scale, (np.abs(got - want).max(), scale)
+    assert np.abs(got - want).mean() <= 1e-3 * scale
+
+
+def test_bf16_vs_fp32_oracle_accuracy_statement(gpu, scale_layers):
+    """configs[3] tolerance check vs the CPU convertRoutine (fp32): stated, not silently chosen --
+    max |bf16 - oracle32| <= 2e-2 and PSNR >= 45 dB on [0,1] data for the 7-layer scale2.0x topology."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(96, 128, 3)
+    want = orc.Oracle(scale_layers).convert(x)
+    got = ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16))
+    err = float(np.abs(got - want).max())
+    p = psnr(got, want)
+    print("bf16 vs oracle32: max abs err %.4g, PSNR %.1f dB, max|want| %.3f" % (err, p, np.abs(want).max()))
+    assert err <= 2e-2 and p >= 45.0, (err, p)
+    # banding / nn2x compose with bf16 exactly as with fp32
+    assert np.array_equal(got, ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16, band_rows=17)))
+    half = np.ascontiguousarray(x[::2, ::2])
+    up = np.repeat(np.repeat(half, 2, 0), 2, 1)
+    assert np.array_equal(ms.convert_nn2x(half, gpu.make_opts(precision=gpu.PRECISION_BF16)),
+                          ms.convert(up, opts=gpu.make_opts(precision=gpu.PRECISION_BF16)))
+
+
+def test_bf16_unsupported_shapes_are_rejected(gpu):
+    ms = gpu._ModelSet.from_layers(small_layers([1, 5, 1], 2))
+    with pytest.raises(gpu.W2xcError) as e:
+        ms.convert(rand_plane(8, 8, 0), opts=gpu.make_opts(precision=gpu.PRECISION_BF16))
+    assert e.value.code == gpu.ERR_UNSUPPORTED
+    ms2 = gpu._ModelSet.from_layers(small_layers([1, 32, 1], 2))
+    with pytest.raises(gpu.W2xcError) as e:
+        ms2.filter(0, rand_plane(8, 8, 0)[None], gpu.make_opts(precision=gpu.PRECISION_BF16))
+    assert e.value.code == gpu.ERR_UNSUPPORTED

@@ -66,6 +66,7 @@ struct DevLayer {
     W2xcKernelKind fast = W2XC_K_DIRECT;
     float *w_fast = nullptr;
     float *w_direct = nullptr;
+    float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
     float *bias = nullptr;
 };
 
@@ -92,6 +93,7 @@ struct DevCtx {
         for (auto &l : layers) {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
+            if (l.w_bf16) hipFree(l.w_bf16);
             if (l.bias) hipFree(l.bias);
         }
         for (int i = 0; i < 2; i++)
@@ -146,7 +148,17 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     if (o.kernel == W2XC_KERNEL_DIRECT) return W2XC_K_DIRECT;
-    return w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout);
+    const W2xcKernelKind k = w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout);
+    if (o.precision == W2XC_PRECISION_BF16) {
+        // bf16 activations live only BETWEEN layers: the first layer reads the caller's fp32 plane, the
+        // last one writes it; anything else (or a shape without an MFMA kernel) is unsupported
+        const int n = (int)m->layers.size();
+        if (l == 0 && k == W2XC_K_FIRST && m->layers[l].nin == 1) return W2XC_K_FIRST_BF16OUT;
+        if (l == n - 1 && k == W2XC_K_LAST && m->layers[l].nout == 1) return W2XC_K_LAST_BF16IN;
+        if (l > 0 && l < n - 1 && k == W2XC_K_MFMA) return W2XC_K_MFMA_BF16;
+        return W2XC_K_DIRECT;   // run_rows rejects this for bf16
+    }
+    return k;
 }
 
 int upload(const std::vector<float> &h, float **d)
@@ -220,10 +232,16 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, bool profile)
 {
-    const DevLayer &dl = c->layers[l];
+    DevLayer &dl = c->layers[l];
     d.cin = m->layers[l].nin;
     d.cout = m->layers[l].nout;
-    d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
+    if (kind == W2XC_K_MFMA_BF16 && !dl.w_bf16) {
+        std::vector<float> pk(w2xc_packed_weight_floats(kind, d.cin, d.cout));
+        w2xc_pack_weights(kind, d.cin, d.cout, m->layers[l].w.data(), pk.data());
+        int rc = upload(pk, &dl.w_bf16);
+        if (rc) return rc;
+    }
+    d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
     d.bias = dl.bias;
     ProfEvent ev;
     if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
@@ -250,7 +268,16 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     for (int l = 1; l < n; l++)
         if (m->layers[l].nin != m->layers[l - 1].nout)
             return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
-    if (o.precision != W2XC_PRECISION_FP32) return fail(W2XC_ERR_UNSUPPORTED, "only W2XC_PRECISION_FP32 is implemented");
+    const bool bf16 = (o.precision == W2XC_PRECISION_BF16);
+    if (o.precision != W2XC_PRECISION_FP32 && !bf16) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
+    if (bf16) {
+        if (n < 2 || m->layers[n - 1].nout != 1) return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16 needs >= 2 layers ending in one plane");
+        for (int l = 0; l < n; l++)
+            if (layer_kind(m, l, o) == W2XC_K_DIRECT)
+                return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16: layer %d (%d->%d) has no bf16 kernel (1->{32,64,128}, {32,64,128}->{32,64,128}, ->1 only)",
+                            l + 1, m->layers[l].nin, m->layers[l].nout);
+    }
+    const size_t esz_div = bf16 ? 2 : 1;   // workspace elements per float slot
 
     // floats per band row for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
     auto ws_need = [&](int rows, size_t need[2]) {
@@ -267,14 +294,14 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         const size_t budget = (size_t)(o.workspace_mb > 0 ? o.workspace_mb : 16384) << 20;
         size_t need[2];
         ws_need(total, need);
-        if ((need[0] + need[1]) * sizeof(float) <= budget) band = total;
+        if ((need[0] + need[1]) * sizeof(float) / esz_div <= budget) band = total;
         else {
             // bytes grow linearly in rows: solve on two probes
             size_t n1[2], n2[2];
             ws_need(1, n1);
             ws_need(2, n2);
-            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1])) * sizeof(float);
-            const double base = (double)(n1[0] + n1[1]) * sizeof(float) - per_row;
+            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1])) * sizeof(float) / esz_div;
+            const double base = (double)(n1[0] + n1[1]) * sizeof(float) / esz_div - per_row;
             band = (int)std::floor(((double)budget - base) / per_row);
             if (band < 1) band = 1;
             const int nb = (total + band - 1) / band;
@@ -286,7 +313,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         size_t need[2];
         ws_need(band, need);
         for (int i = 0; i < 2; i++)
-            if (need[i]) { int rc = ensure_ws(c, i, need[i]); if (rc) return rc; }
+            if (need[i]) { int rc = ensure_ws(c, i, (need[i] + esz_div - 1) / esz_div); if (rc) return rc; }
     }
 
     for (int y0 = ra; y0 < rb; y0 += band) {
@@ -669,6 +696,8 @@ int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *co
     if (!in_planes || !out_planes || w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "bad argument");
     if (in_stride_bytes < (size_t)w * 4 || out_stride_bytes < (size_t)w * 4) return fail(W2XC_ERR_ARG, "bad stride");
     const w2xc_opts o = resolve_opts(opts);
+    if (o.precision != W2XC_PRECISION_FP32)   // Model::filter hands fp32 planes in and out of EVERY layer
+        return fail(W2XC_ERR_UNSUPPORTED, "w2xc_layer_filter is fp32 only (bf16 activations exist only between layers of w2xc_convert_*)");
     if (w2xc_device_count() <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
     int dev = o.device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));

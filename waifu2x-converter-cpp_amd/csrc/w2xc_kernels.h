@@ -32,6 +32,10 @@ enum W2xcKernelKind {
     W2XC_K_MFMA = 1,     // cin, cout in {32,64,128}; NHWC in/out; fp32 MFMA implicit GEMM
     W2XC_K_FIRST = 2,    // cin <= 3 -> cout multiple of 32: planar in, NHWC out, fp32 MFMA (K = 9*cin)
     W2XC_K_LAST = 3,     // cin multiple of 32 -> cout <= 3: NHWC in, planar out, taps-as-N fp32 MFMA
+    // W2XC_PRECISION_BF16: activations between layers are NHWC bf16 (strides still in ELEMENTS), fp32 accumulate
+    W2XC_K_MFMA_BF16 = 4,      // cin, cout in {32,64,128}: bf16 in/out, bf16 weights, v_mfma_f32_32x32x16_bf16
+    W2XC_K_FIRST_BF16OUT = 5,  // W2XC_K_FIRST (fp32 planar in, fp32 weights) storing bf16 NHWC
+    W2XC_K_LAST_BF16IN = 6,    // W2XC_K_LAST reading bf16 NHWC (widened to fp32 exactly), fp32 planar out
 };
 
 // Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
