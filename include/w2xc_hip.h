@@ -118,6 +118,16 @@ int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_str
                              int view_y0, int w, int plane_h, int row_begin, int row_end, float *d_out,
                              size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);
 
+/* Multi-plane generalisation (BASELINE.json configs[4]: a 3 -> 128 -> ... -> 3 model).  The reference
+ * can only reach such a model by chaining Model::filter by hand (convertWithModels pushes one plane,
+ * convertRoutine.cpp:63-64, and returns only outputPlanes[0], :78); this runs the same wrapper --
+ * replicate pad by the layer count, all layers, crop -- on n_in_planes planar DEVICE planes and writes
+ * ALL planes of the last layer, planar.  With one input plane and a one-plane last layer it equals
+ * w2xc_convert_plane_device.  fp32 only. */
+int w2xc_convert_planes_device(w2xc_model *m, int n_in_planes, const float *d_in, size_t in_plane_stride_bytes,
+                               size_t in_stride_bytes, int w, int h, float *d_out, size_t out_plane_stride_bytes,
+                               size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);
+
 /* N1: the scale loop of the CLI -- cv::resize(INTER_NEAREST, 2x) of the luma plane
  * (main.cpp:132-140) followed by convertWithModels (:148) -- as ONE call.  `in` is the h x w plane
  * BEFORE the resize, `out` is 2h x 2w.  The nearest-neighbour upscale is folded into layer 1's load

@@ -355,3 +355,27 @@ def test_bf16_unsupported_shapes_are_rejected(gpu):
     with pytest.raises(gpu.W2xcError) as e:
         ms2.filter(0, rand_plane(8, 8, 0)[None], gpu.make_opts(precision=gpu.PRECISION_BF16))
     assert e.value.code == gpu.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("planes", [[3, 128, 128, 3], [3, 32, 64, 2], [2, 5, 4], [1, 32, 32]])
+def test_multi_plane_wrapper(gpu, planes):
+    """w2xc_convert_planes_device (configs[4] boundary): pad n / layers / crop on several planes equals the
+    reference's only route to such a model -- chaining Model::filter on the replicate-padded planes."""
+    torch = pytest.importorskip("torch")
+    layers = small_layers(planes, 900 + sum(planes))
+    n = len(layers)
+    ms = gpu._ModelSet.from_layers(layers)
+    h, w = 30, 44
+    x = np.random.default_rng(8).random((planes[0], h, w), dtype=np.float32)
+    o = orc.Oracle(layers)
+    t = np.pad(x, ((0, 0), (n, n), (n, n)), mode="edge")
+    for l in range(n):
+        t = o.filter(l, t, njob=4)
+    want = t[:, n:n + h, n:n + w]
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((planes[-1], h, w), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    ms.convert_planes_device(planes[0], d_in.data_ptr(), h * w * 4, w * 4, w, h, d_out.data_ptr(), h * w * 4, w * 4,
+                             stream=st.cuda_stream, opts=gpu.make_opts(device=0))
+    st.synchronize()
+    assert_close(d_out.cpu().numpy(), want, "planes %s" % planes)

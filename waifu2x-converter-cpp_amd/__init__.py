@@ -75,6 +75,7 @@ def _load():
         "w2xc_get_block_size": (None, [C.POINTER(ci), C.POINTER(ci)]),
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
+        "w2xc_convert_planes_device": (ci, [vp, ci, fp, cs, cs, ci, ci, fp, cs, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_plane_nn2x": (ci, [vp, fp, cs, ci, ci, fp, cs, C.POINTER(Opts)]),
         "w2xc_convert_plane_nn2x_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_rows_device": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
@@ -224,6 +225,16 @@ class _ModelSet:
         if rc != OK:
             raise W2xcError(rc, last_error())
         return out
+
+    def convert_planes_device(self, n_in, d_in, in_plane_stride_bytes, in_stride_bytes, w, h, d_out,
+                              out_plane_stride_bytes, out_stride_bytes, stream=0, opts=None):
+        """Multi-plane wrapper (pad n / all layers / crop) on planar device planes; writes every plane of the
+        last layer (w2xc_convert_planes_device)."""
+        rc = _lib.w2xc_convert_planes_device(self.handle, n_in, C.c_void_p(d_in), in_plane_stride_bytes, in_stride_bytes, w, h,
+                                             C.c_void_p(d_out), out_plane_stride_bytes, out_stride_bytes, C.c_void_p(stream),
+                                             C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
 
     def convert_nn2x(self, plane, opts=None):
         """cv::resize(INTER_NEAREST, 2x) + convertWithModels (main.cpp:132-148) in one call: h x w -> 2h x 2w."""

@@ -258,13 +258,18 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
 // [vy0, vy0+vh) -- every row in [ra-n, rb+n) clipped to the plane must be inside the view.
 // `up` = 1 folds a nearest-neighbour 2x (main.cpp:132-140) into layer 1: vh, vy0, w, ra, rb are then in
 // UPSCALED coordinates while d_in holds the (vh/2) x (w/2) source rows starting at source row vy0/2.
+// Multi-plane form (w2xc_convert_planes_*): n_in planar input planes `in_cs` floats apart, ALL planes of the
+// last layer written planar `out_cs` floats apart.  n_in == 1 && out_cs == 0 is convertWithModels proper,
+// which returns only outputPlanes[0] (convertRoutine.cpp:78).
 int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,
-             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o, int up = 0)
+             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o, int up = 0, int n_in = 1,
+             long long in_cs = 0, long long out_cs = 0)
 {
     const int n = (int)m->layers.size();
     if (n == 0) return fail(W2XC_ERR_ARG, "model has no layers");
-    if (m->layers[0].nin != 1)   // convertWithModelsBasic pushes exactly one plane (convertRoutine.cpp:63-64)
-        return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n1,%d", m->layers[0].nin);
+    if (m->layers[0].nin != n_in)   // convertWithModelsBasic pushes exactly one plane (convertRoutine.cpp:63-64)
+        return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", n_in, m->layers[0].nin);
+    const bool all_out = out_cs != 0;   // multi-plane output
     for (int l = 1; l < n; l++)
         if (m->layers[l].nin != m->layers[l - 1].nout)
             return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
@@ -279,11 +284,17 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     }
     const size_t esz_div = bf16 ? 2 : 1;   // workspace elements per float slot
 
+    // the last layer stores straight into the caller's planar plane(s) when its kernel can address planar
+    // output (conv3x3_last / conv3x3_direct); otherwise it goes through the NHWC workspace + a repack
+    const W2xcKernelKind last_kind = layer_kind(m, n - 1, o);
+    const bool last_direct = (m->layers[n - 1].nout == 1 || all_out) &&
+                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_BF16IN || last_kind == W2XC_K_DIRECT ||
+                              (m->layers[n - 1].nout == 1 && last_kind != W2XC_K_MFMA && last_kind != W2XC_K_FIRST));
     // floats per band row for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
     auto ws_need = [&](int rows, size_t need[2]) {
         need[0] = need[1] = 0;
         for (int k = 1; k <= n; k++) {
-            if (k == n && m->layers[n - 1].nout == 1) break;   // written straight to d_out
+            if (k == n && last_direct) break;   // written straight to d_out
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * m->layers[k - 1].nout);
         }
@@ -319,7 +330,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     for (int y0 = ra; y0 < rb; y0 += band) {
         const int y1 = std::min(rb, y0 + band);
         const float *src = d_in;
-        long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = 0;
+        long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs;
         int src_h = vh, src_w = w;
         for (int k = 1; k <= n; k++) {
             if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
@@ -333,10 +344,10 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.off_y = k == 1 ? (y0 - n - vy0) : 0;
             d.off_x = k == 1 ? -n : 0;
             d.in_shift = k == 1 ? up : 0;
-            const bool direct_out = (k == n && hl.nout == 1);
+            const bool direct_out = (k == n && last_direct);
             if (direct_out) {
                 d.out = d_out + (size_t)(y0 - ra) * out_stride_f;
-                d.out_rs = (long long)out_stride_f; d.out_ps = 1; d.out_cs = 0;
+                d.out_rs = (long long)out_stride_f; d.out_ps = 1; d.out_cs = out_cs;
             } else {
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
@@ -346,7 +357,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (k == n && !direct_out) {
                 // outputPlanes[0] of a multi-plane last layer (convertRoutine.cpp:78)
                 hipError_t e = w2xc_launch_repack(d.out, d.out_rs, d.out_ps, 1, d_out + (size_t)(y0 - ra) * out_stride_f,
-                                                  (long long)out_stride_f, 1, 0, d.out_h, d.out_w, 1, st);
+                                                  (long long)out_stride_f, 1, out_cs, d.out_h, d.out_w, all_out ? hl.nout : 1, st);
                 if (e != hipSuccess) return fail(W2XC_ERR_HIP, "repack launch failed: %s", hipGetErrorString(e));
             }
             src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs;
@@ -657,6 +668,29 @@ int w2xc_convert_plane_nn2x(w2xc_model *m, const float *in, size_t in_stride_byt
                             size_t out_stride_bytes, const w2xc_opts *opts)
 {
     return convert_plane_host(m, in, in_stride_bytes, w, h, out, out_stride_bytes, opts, 1);
+}
+
+int w2xc_convert_planes_device(w2xc_model *m, int n_in_planes, const float *d_in, size_t in_plane_stride_bytes,
+                               size_t in_stride_bytes, int w, int h, float *d_out, size_t out_plane_stride_bytes,
+                               size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts)
+{
+    int rc = check_plane_args(m, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes);
+    if (rc) return rc;
+    if (n_in_planes < 1 || (in_plane_stride_bytes & 3) || (out_plane_stride_bytes & 3) ||
+        (n_in_planes > 1 && in_plane_stride_bytes < in_stride_bytes * (size_t)h) || out_plane_stride_bytes < out_stride_bytes * (size_t)h)
+        return fail(W2XC_ERR_ARG, "bad plane count / plane strides");
+    const w2xc_opts o = resolve_opts(opts);
+    if (o.precision != W2XC_PRECISION_FP32) return fail(W2XC_ERR_UNSUPPORTED, "w2xc_convert_planes_* is fp32 only");
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o, 0,
+                    n_in_planes, (long long)(in_plane_stride_bytes / 4), (long long)(out_plane_stride_bytes / 4));
 }
 
 int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h, float *d_out,
