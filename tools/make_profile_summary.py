@@ -23,7 +23,7 @@ stats = {r["Name"]: r for r in csv.DictReader(open(base + "trace/trace_kernel_st
 out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (tools/profile.sh)",
        "note": __doc__.split("FETCH_SIZE", 1)[1].strip().replace("\n", " "), "kernels": {}}
 for k, (cin, cout) in enumerate(PLANES, 1):
-    sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d>" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
+    sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
     names = [n for n in stats if sub in n and n.startswith("void conv3x3")]
     if not names:
         continue

@@ -281,22 +281,20 @@ static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned v
                  : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
                  : "memory", "m0");
 }
-#ifndef V2_PIN_READS
-#define V2_PIN_READS 0
-#endif
 #define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int ABL = 0>
-__global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
+template <int CIN, int COUT, int MB, int NB, int WM, int WN>
+__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
     constexpr int NSL = CIN / 32, NBT = COUT / 32;
-    constexpr int APW = 11;                          // A pieces (1 KiB) per wave per slice: 44 >= 42.5
-    constexpr unsigned A_BYTES = 4 * APW * 1024;     // 45056
-    constexpr int BPW = NBT;                         // B pieces per wave per stage (4*NBT in total)
+    constexpr int NW = WM * WN;                      // 4 waves (one per SIMD) or 8 (two per SIMD)
+    constexpr int APW = (43 + NW) / NW;              // A pieces (1 KiB) per wave per slice: NW*APW >= 42.5
+    constexpr unsigned A_BYTES = NW * APW * 1024;    // 45056 (4 waves) / 49152 (8 waves)
+    constexpr int BPW = 4 * NBT / NW;                // B pieces per wave per stage (4*NBT in total)
     constexpr unsigned B_BYTES = 4 * NBT * 1024;
     constexpr unsigned B_BASE = 2 * A_BYTES;
-    static_assert(WM * WN == 4 && MB * WM == ROWS && NB * WN == NBT, "tile shape");
+    static_assert((NW == 4 || NW == 8) && MB * WM == ROWS && NB * WN == NBT && BPW * NW == 4 * NBT, "tile shape");
     static_assert(CIN % 32 == 0 && COUT % 32 == 0, "planes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
@@ -327,7 +325,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
         const int ty_ = t / tiles_x, tx_ = t - ty_ * tiles_x;
 #pragma unroll
         for (int jj = 0; jj < APW; jj++) {
-            const int s = (jj * 4 + wave) * 64 + lane;            // 16-byte slot in the A buffer
+            const int s = (jj * NW + wave) * 64 + lane;           // 16-byte slot in the A buffer
             int p = s >> 3;
             p = p < NPIX ? p : NPIX - 1;                           // slots past the tile re-read its last pixel
             const int q = (s & 7) ^ ((p >> 1) & 7);                // chunk stored at this position
@@ -350,7 +348,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
         }
     };
     auto dma_a = [&](unsigned add, unsigned abuf, int jj) {
-        lds_dma16(in4 + goff[jj] + add, lds0 + abuf * A_BYTES + (unsigned)(jj * 4 + wave) * 1024u);
+        lds_dma16(in4 + goff[jj] + add, lds0 + abuf * A_BYTES + (unsigned)(jj * NW + wave) * 1024u);
     };
 
     // ---- fragment addressing ----
@@ -416,8 +414,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
             const int tap3 = (tap + 3) % 9;
             const int sl3 = (tap + 3 < 9) ? sl : sl_next;
             const unsigned buf = gs & 3u, buf3 = (gs + 3u) & 3u, buf1 = (gs + 1u) & 3u;
-            constexpr int KA[9] = {2, 2, 2, 2, 2, 1, 0, 0, 0};
-            const int ja0 = tap * 2;   // first A piece of this stage (valid while tap < 6)
+            // A pieces of the next slice are issued on taps 0..5: KA[t] = ceil-spread of APW over 6 stages
+            constexpr int KA[9] = {(APW + 5) / 6, (APW + 4) / 6, (APW + 3) / 6, (APW + 2) / 6, (APW + 1) / 6, APW / 6, 0, 0, 0};
+            int ja0 = 0;               // first A piece of this stage
+#pragma unroll
+            for (int t = 0; t < 9; t++) ja0 += t < tap ? KA[t] : 0;
 #pragma unroll
             for (int c8 = 0; c8 < 4; c8++) {
                 // One step = M MFMAs.  Every other instruction is pinned into an MFMA shadow:
@@ -440,20 +441,19 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
                             const int m = (j * MB + mb) * NB + nb;        // MFMA index in the step
                             if (c8 == 0 && (m == 1 || m == 3) && (m >> 1) < KA[tap]) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(ABL & 4)) dma_a(a_add, abuf ^ 1u, ja0 + (m >> 1));
+                                dma_a(a_add, abuf ^ 1u, ja0 + (m >> 1));
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if (m == (c8 == 0 ? 5 : 1) && c8 < BPW) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(ABL & 4)) dma_b(sl3, tap3, buf3, c8);
+                                dma_b(sl3, tap3, buf3, c8);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
                             for (int r = 0; r < R; r++) {
                                 if (m == 6 + (r * (M - 8)) / R) {         // reads spread over MFMAs 6 .. M-3
                                     __builtin_amdgcn_sched_barrier(0);
-                                    if (ABL & 8) { if (r < MB) a_nxt[r] = a_cur[r]; else b_nxt[r - MB] = b_cur[r - MB]; }
-                                    else if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
+                                    if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
                                     else b_nxt[r - MB] = *b_addr(bbuf_n, c8_n, r - MB);
                                     __builtin_amdgcn_sched_barrier(0);
                                 }
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
                 case 5: W2XC_WAIT_VMCNT(5); break;
                 default: W2XC_WAIT_VMCNT(6); break;
                 }
-                if (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             gs++;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
             const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
             const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
             float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
-            if (interior && !(ABL & 2)) {
+            if (interior) {
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma2(W2xcConvDesc d, int tile
                         for (int r = 0; r < 16; r++) {
                             const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                             const float v = acc[mb][nb][r] + bv[nb];
-                            if ((ABL & 2) ? (x < -12345) : (y < d.out_h && x < d.out_w))
+                            if (y < d.out_h && x < d.out_w)
                                 obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
                             acc[mb][nb][r] = 0.0f;
                         }
@@ -944,13 +944,14 @@ static hipError_t launch_mfma(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int ABL = 0>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN>
 static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
-    const size_t lds_bytes = 2 * 45056 + 4 * (size_t)(4 * (COUT / 32) * 1024);
-    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, ABL>;
+    constexpr int NW = WM * WN;
+    const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024);
+    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -959,12 +960,11 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, d, tiles_x, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
     return hipGetLastError();
 }
 
-// W2XC_MFMA_V2: unset = pick per shape (v2 everywhere except 32->32, where the v1 tiling measured
-// faster), 0 = force conv3x3_mfma (v1), 1 = force conv3x3_mfma2, >= 10 = ablation builds (tuning only)
+// W2XC_MFMA_V2 (tuning aid): unset = default tilings, 0 = force conv3x3_mfma (v1), 1 = conv3x3_mfma2 with 4 waves
 static int mfma_v2_enabled()
 {
     static int v = -2;
@@ -1002,27 +1002,23 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
     if (kind == W2XC_K_MFMA) {
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
+        // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0.  Measured inside the 7-layer model:
+        // 8 waves (two per SIMD) win on 128->128 only, 4 waves elsewhere (W2XC_MFMA_V2=3 forces 8 where
+        // the plane-block count divides, =1 forces 4); 32->32 stays on conv3x3_mfma (measured faster).
         const int v2 = mfma_v2_enabled();
-        if (v2 > 0 || (v2 < 0 && key != 32032)) {
+        if (v2 != 0) {
+            const bool w8 = (v2 == 3) || (v2 < 0 && key == 128128);
             switch (key) {
-            //                            CIN  COUT  MB NB WM WN
-            case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
-            case 32064:  return launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
-            case 32128:  return launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
+            //                                  CIN  COUT  MB NB WM WN
+            case 32032:  if (v2 > 0) return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream); break;
+            case 32064:  return w8 ? launch_mfma2<32, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
+            case 32128:  return w8 ? launch_mfma2<32, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
             case 64032:  return launch_mfma2<64, 32, 2, 1, 4, 1>(d, stream);
-            case 64064:  return launch_mfma2<64, 64, 2, 2, 4, 1>(d, stream);
-            case 64128:  return launch_mfma2<64, 128, 4, 2, 2, 2>(d, stream);
+            case 64064:  return w8 ? launch_mfma2<64, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<64, 64, 2, 2, 4, 1>(d, stream);
+            case 64128:  return w8 ? launch_mfma2<64, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<64, 128, 4, 2, 2, 2>(d, stream);
             case 128032: return launch_mfma2<128, 32, 2, 1, 4, 1>(d, stream);
-            case 128064: return launch_mfma2<128, 64, 2, 2, 4, 1>(d, stream);
-            case 128128:
-                switch (mfma_v2_enabled()) {
-                case 11: return launch_mfma2<128, 128, 4, 2, 2, 2, 1>(d, stream);    // ablations (wrong results)
-                case 12: return launch_mfma2<128, 128, 4, 2, 2, 2, 2>(d, stream);
-                case 14: return launch_mfma2<128, 128, 4, 2, 2, 2, 4>(d, stream);
-                case 18: return launch_mfma2<128, 128, 4, 2, 2, 2, 8>(d, stream);
-                case 25: return launch_mfma2<128, 128, 4, 2, 2, 2, 15>(d, stream);
-                default: return launch_mfma2<128, 128, 4, 2, 2, 2>(d, stream);
-                }
+            case 128064: return w8 ? launch_mfma2<128, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<128, 64, 2, 2, 4, 1>(d, stream);
+            case 128128: return w8 ? launch_mfma2<128, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<128, 128, 4, 2, 2, 2>(d, stream);
             default: break;
             }
         }
