@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic; NOT the headline number: the reference "
                          "computes in fp32 and `value` is only valid for the default)")
-    ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane"],
+    ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane", "image_u8"],
                     help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
                          "ranks (BASELINE.json configs[2] with --width 8192 --height 8192): strong scaling")
     args = ap.parse_args()
@@ -173,7 +173,16 @@ def main():
     stream = torch.cuda.current_stream()
     opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows,
                           precision=w2xc.PRECISION_BF16 if args.precision == "bf16" else w2xc.PRECISION_FP32)
-    if sharded:
+    if args.workload == "image_u8":
+        # N2: uint8 RGB frame in HBM -> uint8 2x frame in HBM (colour conversion, bicubic U/V, CNN on Y, back to uint8)
+        rgb = np.random.default_rng(2 + rank).integers(0, 256, size=(args.height, args.width, 3), dtype=np.uint8)
+        d_in = torch.from_numpy(rgb).cuda()
+        d_out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+
+        def step():
+            ms.scale2x_image_u8_device(d_in.data_ptr(), args.width * 3, args.width, args.height, d_out.data_ptr(), W * 3, 1,
+                                       stream=stream.cuda_stream, opts=opts)
+    elif sharded:
         # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo) is resident in HBM
         ra, rb = w2xc.shard_rows(H, world, rank)
         y0, y1 = w2xc.shard_view(H, ra, rb, n_layers)
@@ -211,7 +220,7 @@ def main():
         elapsed = float(t.item())
 
     layer_ms, launches = ms.profile_read(dev_index)
-    ok = bool(torch.isfinite(d_out).all().item())
+    ok = bool(torch.isfinite(d_out.float()).all().item())
 
     if rank == 0:
         in_px = args.height * args.width
@@ -249,7 +258,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 activations/weights between layers, f32 accumulate (not the headline precision)",
             "data": "synthetic",
-            "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
+            "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU): " if args.workload == "image_u8" else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
                                    "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
                                    "planes resident in HBM" % (args.width, args.height, W, H),
                        "cnn_plane": [H, W], "frames_per_step": 1 if sharded else world, "bands_per_frame": max(bands, 1),

@@ -139,6 +139,26 @@ int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_s
                                    float *d_out, size_t out_stride_bytes, void *hip_stream,
                                    const w2xc_opts *opts);
 
+/* N2: the whole SCALE PHASE of the CLI for one image, device-resident:
+ *   convertTo(CV_32F, 1/255) + cvtColor(COLOR_RGB2YUV) on the three channels as given  (main.cpp:75-76)
+ *   `iterations` times: Y <- convertWithModels(resize(Y, 2x, INTER_NEAREST)),
+ *                       U, V <- resize(2x, INTER_CUBIC)                                  (main.cpp:126-156)
+ *   cvtColor(COLOR_YUV2RGB) + convertTo(CV_8U, 255)  (the only clip, Q2)                 (main.cpp:171-172)
+ * `in` is h rows of w interleaved 3-channel uint8 pixels, `out` is (h << iterations) rows of (w << iterations).
+ * The image stays float YUV between iterations, exactly like the reference.  The *_device form takes device
+ * pointers and is asynchronous on `hip_stream`; the host form uses opts->device (default: current). */
+int w2xc_scale2x_image_u8_device(w2xc_model *scale_model, const unsigned char *d_in, size_t in_stride_bytes, int w, int h,
+                                 unsigned char *d_out, size_t out_stride_bytes, int iterations, void *hip_stream,
+                                 const w2xc_opts *opts);
+int w2xc_scale2x_image_u8(w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
+                          unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts);
+/* the building blocks on contiguous float planes (device pointers): main.cpp:144 on one plane, :75-76, :171-172 */
+int w2xc_resize2x_cubic_device(const float *d_src, int w, int h, float *d_dst, void *hip_stream);
+int w2xc_u8_to_yuv_device(const unsigned char *d_in, size_t in_stride_bytes, int w, int h, float *d_y, float *d_u,
+                          float *d_v, void *hip_stream);
+int w2xc_yuv_to_u8_device(const float *d_y, const float *d_u, const float *d_v, int w, int h, unsigned char *d_out,
+                          size_t out_stride_bytes, void *hip_stream);
+
 /* == Model::filter(inputPlanes, outputPlanes) for layer `layer` (modelHandler.cpp:26-72):
  * n_in_planes host planes of h x w floats in, nout planes out, SAME size, per-layer
  * BORDER_REPLICATE (:141-142), bias, LeakyReLU(0.1) (:147-152).  Returns W2XC_ERR_PLANES when

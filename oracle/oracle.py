@@ -164,3 +164,60 @@ class RefBuild:
         out = np.empty((self.planes(layer)[1], h, w), np.float32)
         rc = self.lib.w2xc_ref_filter(self.h, layer, n, planes.ctypes.data, w, h, out.ctypes.data, njob)
         return out if rc == 0 else None
+
+
+# ---- N2: colour front/back end and U/V resize of the CLI scale loop (w2xc_oracle_color.c) ---------------
+def _color_lib():
+    if not os.path.exists(ORACLE_SO):
+        build()
+    lib = C.CDLL(ORACLE_SO)
+    if not hasattr(lib, "w2xc_oracle_u8_to_yuv"):
+        build()
+        lib = C.CDLL(ORACLE_SO)
+    return lib
+
+
+def u8_to_yuv(img):
+    """main.cpp:75-76 (+split): h x w x 3 uint8 -> (Y, U, V) float32 planes."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+    y, u, v = (np.empty((h, w), np.float32) for _ in range(3))
+    _color_lib().w2xc_oracle_u8_to_yuv(C.c_void_p(img.ctypes.data), C.c_size_t(w * 3), w, h, C.c_void_p(y.ctypes.data),
+                                      C.c_void_p(u.ctypes.data), C.c_void_p(v.ctypes.data))
+    return y, u, v
+
+
+def yuv_to_u8(y, u, v):
+    """main.cpp:171-172 (+merge): float32 planes -> h x w x 3 uint8."""
+    y, u, v = (np.ascontiguousarray(a, dtype=np.float32) for a in (y, u, v))
+    h, w = y.shape
+    out = np.empty((h, w, 3), np.uint8)
+    _color_lib().w2xc_oracle_yuv_to_u8(C.c_void_p(y.ctypes.data), C.c_void_p(u.ctypes.data), C.c_void_p(v.ctypes.data), w, h,
+                                      C.c_void_p(out.ctypes.data), C.c_size_t(w * 3))
+    return out
+
+
+def resize2x_cubic(plane):
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    h, w = plane.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    _color_lib().w2xc_oracle_resize2x_cubic(C.c_void_p(plane.ctypes.data), w, h, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def resize2x_nearest(plane):
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    h, w = plane.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    _color_lib().w2xc_oracle_resize2x_nearest(C.c_void_p(plane.ctypes.data), w, h, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def scale2x_image_u8(oracle, img, iterations=1):
+    """The CLI's scale phase on a uint8 image (main.cpp:74-76,126-156,171-172): the image stays float YUV
+    between 2x iterations; only the final convertTo clips."""
+    y, u, v = u8_to_yuv(img)
+    for _ in range(iterations):
+        y = oracle.convert(resize2x_nearest(y))
+        u, v = resize2x_cubic(u), resize2x_cubic(v)
+    return yuv_to_u8(y, u, v)

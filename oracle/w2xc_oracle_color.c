@@ -1,0 +1,125 @@
+/*
+ * w2xc_oracle_color.c -- CPU restatement of the colour front/back end and the U/V resize of the reference
+ * CLI's scale loop (row N2 of SURVEY.md 8f).  TEST INFRASTRUCTURE ONLY (see w2xc_oracle.c).
+ *
+ * Reference call sites (/root/reference/src/main.cpp):
+ *   :75   image.convertTo(image, CV_32F, 1.0/255.0)
+ *   :76   cv::cvtColor(image, image, cv::COLOR_RGB2YUV)     (applied to imread's BGR data as-is, Q3)
+ *   :136  cv::resize(image, image2xNearest, 2x, INTER_NEAREST)   -> Y plane for the CNN
+ *   :144  cv::resize(image, image2xBicubic, 2x, INTER_CUBIC)     -> U, V planes
+ *   :171  cv::cvtColor(image, image, cv::COLOR_YUV2RGB)
+ *   :172  image.convertTo(image, CV_8U, 255.0)              (the only clip in the pipeline, Q2)
+ *
+ * PARITY UNPINNED: these are OpenCV 3.0 imgproc/core functions (un-vendored, absent here, no golden
+ * vectors in the reference).  Restated from OpenCV's documented float paths:
+ *   convertTo 8U->32F:  (float)u * (float)(1/255.0)   [cvtScale_ with a float work type]
+ *   RGB2YUV (float):    Y = c0*0.299f + c1*0.587f + c2*0.114f; U = (c2 - Y)*0.492f + 0.5f; V = (c0 - Y)*0.877f + 0.5f
+ *                       (channel 0 is whatever the caller calls "R"; dst order Y,U,V)
+ *   YUV2RGB (float):    c2 = Y + (U-0.5f)*2.032f; c1 = Y + (U-0.5f)*-0.395f + (V-0.5f)*-0.581f; c0 = Y + (V-0.5f)*1.140f
+ *   convertTo 32F->8U:  saturate_cast<uchar>(cvRound(v * 255.f))   (round half to even)
+ *   resize INTER_CUBIC: fx = (dx+0.5)*0.5 - 0.5; sx = floor(fx); t = fx - sx; Keys cubic with A = -0.75;
+ *                       taps sx-1..sx+2 with indices clipped to the image (replicate); horizontal pass
+ *                       to float rows, then vertical pass; each pass is a left-to-right sum of 4 products.
+ *   resize INTER_NEAREST 2x: src(y>>1, x>>1).
+ * Compile with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* main.cpp:75-76 + cv::split: interleaved 3-channel u8 (row stride in bytes) -> planar Y,U,V floats */
+void w2xc_oracle_u8_to_yuv(const uint8_t *src, size_t stride, int w, int h, float *y, float *u, float *v)
+{
+    const float s = (float)(1.0 / 255.0);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            const uint8_t *p = src + (size_t)r * stride + (size_t)c * 3;
+            const float c0 = (float)p[0] * s, c1 = (float)p[1] * s, c2 = (float)p[2] * s;
+            float Y = c0 * 0.299f;
+            Y = Y + c1 * 0.587f;
+            Y = Y + c2 * 0.114f;
+            const size_t q = (size_t)r * w + c;
+            y[q] = Y;
+            u[q] = (c2 - Y) * 0.492f + 0.5f;
+            v[q] = (c0 - Y) * 0.877f + 0.5f;
+        }
+}
+
+/* main.cpp:171-172 + cv::merge: planar Y,U,V floats -> interleaved 3-channel u8 */
+void w2xc_oracle_yuv_to_u8(const float *y, const float *u, const float *v, int w, int h, uint8_t *dst, size_t stride)
+{
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            const size_t q = (size_t)r * w + c;
+            const float Y = y[q], U = u[q] - 0.5f, V = v[q] - 0.5f;
+            float ch[3];
+            ch[2] = Y + U * 2.032f;
+            ch[1] = (Y + U * -0.395f) + V * -0.581f;
+            ch[0] = Y + V * 1.140f;
+            uint8_t *p = dst + (size_t)r * stride + (size_t)c * 3;
+            for (int k = 0; k < 3; k++) {
+                const float t = ch[k] * 255.0f;
+                long iv = lrintf(t);                 /* cvRound: round half to even (default FP mode) */
+                p[k] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+            }
+        }
+}
+
+static void cubic_coeffs(float t, float *c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A;
+    c[1] = ((A + 2) * t - (A + 3)) * t * t + 1;
+    c[2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+/* main.cpp:144 on one plane: cv::resize(src, dst, 2x, INTER_CUBIC) */
+void w2xc_oracle_resize2x_cubic(const float *src, int w, int h, float *dst)
+{
+    const int W = 2 * w, H = 2 * h;
+    float *tmp = (float *)malloc((size_t)W * h * sizeof(float));   /* horizontal pass */
+    for (int dx = 0; dx < W; dx++) {
+        float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+        int sx = (int)floorf(fx);
+        float c[4];
+        cubic_coeffs(fx - sx, c);
+        int xs[4];
+        for (int k = 0; k < 4; k++) xs[k] = clampi(sx - 1 + k, 0, w - 1);
+        for (int r = 0; r < h; r++) {
+            const float *S = src + (size_t)r * w;
+            float a = S[xs[0]] * c[0];
+            a = a + S[xs[1]] * c[1];
+            a = a + S[xs[2]] * c[2];
+            a = a + S[xs[3]] * c[3];
+            tmp[(size_t)r * W + dx] = a;
+        }
+    }
+    for (int dy = 0; dy < H; dy++) {
+        float fy = (float)((dy + 0.5) * 0.5 - 0.5);
+        int sy = (int)floorf(fy);
+        float c[4];
+        cubic_coeffs(fy - sy, c);
+        const float *R[4];
+        for (int k = 0; k < 4; k++) R[k] = tmp + (size_t)clampi(sy - 1 + k, 0, h - 1) * W;
+        float *D = dst + (size_t)dy * W;
+        for (int x = 0; x < W; x++) {
+            float a = R[0][x] * c[0];
+            a = a + R[1][x] * c[1];
+            a = a + R[2][x] * c[2];
+            a = a + R[3][x] * c[3];
+            D[x] = a;
+        }
+    }
+    free(tmp);
+}
+
+/* main.cpp:136 on one plane: cv::resize(src, dst, 2x, INTER_NEAREST) */
+void w2xc_oracle_resize2x_nearest(const float *src, int w, int h, float *dst)
+{
+    for (int y = 0; y < 2 * h; y++)
+        for (int x = 0; x < 2 * w; x++) dst[(size_t)y * 2 * w + x] = src[(size_t)(y >> 1) * w + (x >> 1)];
+}

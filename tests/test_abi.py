@@ -151,6 +151,9 @@ def test_no_cpu_fallback_without_gpu(w2xc, noise1_layers):
     assert out.array is None
     outs = []
     assert models[0].filter([w2xc.Mat(rand_plane(8, 8, 0))], outs) is False
+    with pytest.raises(w2xc.W2xcError) as e:
+        ms.scale2x_image_u8(np.zeros((4, 4, 3), np.uint8))
+    assert e.value.code == w2xc.ERR_HIP
 
 
 def test_arbitrary_model_lists_get_their_own_container(w2xc):

@@ -379,3 +379,57 @@ def test_multi_plane_wrapper(gpu, planes):
                              stream=st.cuda_stream, opts=gpu.make_opts(device=0))
     st.synchronize()
     assert_close(d_out.cpu().numpy(), want, "planes %s" % planes)
+
+
+# ---- N2: colour front/back end + bicubic U/V of the CLI scale loop (main.cpp:74-76,136-156,171-172) ----------
+def test_color_building_blocks_bit_exact(gpu):
+    torch = pytest.importorskip("torch")
+    lib = gpu.lib()
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    d_img = torch.from_numpy(img).cuda()
+    planes = torch.empty((3, 37, 53), dtype=torch.float32, device="cuda")
+    assert lib.w2xc_u8_to_yuv_device(d_img.data_ptr(), 53 * 3, 53, 37, planes[0].data_ptr(), planes[1].data_ptr(),
+                                     planes[2].data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    y, u, v = orc.u8_to_yuv(img)
+    got = planes.cpu().numpy()
+    assert np.array_equal(got[0], y) and np.array_equal(got[1], u) and np.array_equal(got[2], v)
+    for (h, w) in [(37, 53), (1, 1), (2, 3)]:
+        src = rng.standard_normal((h, w)).astype(np.float32)
+        d_src = torch.from_numpy(src).cuda()
+        d_dst = torch.empty((2 * h, 2 * w), dtype=torch.float32, device="cuda")
+        assert lib.w2xc_resize2x_cubic_device(d_src.data_ptr(), w, h, d_dst.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d_dst.cpu().numpy(), orc.resize2x_cubic(src)), (h, w)
+    yuv = rng.random((3, 20, 31), dtype=np.float32) * 1.4 - 0.2      # exercises both saturation ends
+    d_yuv = torch.from_numpy(yuv).cuda()
+    d_out = torch.empty((20, 31, 3), dtype=torch.uint8, device="cuda")
+    assert lib.w2xc_yuv_to_u8_device(d_yuv[0].data_ptr(), d_yuv[1].data_ptr(), d_yuv[2].data_ptr(), 31, 20, d_out.data_ptr(), 31 * 3, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), orc.yuv_to_u8(yuv[0], yuv[1], yuv[2]))
+
+
+@pytest.mark.parametrize("iterations", [1, 2])
+def test_scale2x_image_u8_pipeline(gpu, scale_layers, iterations):
+    """whole scale phase on a uint8 image vs the CPU restatement of main.cpp's loop: identical bytes with the
+    reference-ordered direct kernel; with the MFMA kernels the luma differs by ~1e-6, which may move a value
+    across a rounding boundary: at most 1 LSB, on well under 1 % of the bytes."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (24, 36, 3), dtype=np.uint8)
+    want = orc.scale2x_image_u8(orc.Oracle(scale_layers), img, iterations)
+    exact = ms.scale2x_image_u8(img, iterations, direct(gpu))
+    assert exact.shape == want.shape == (24 << iterations, 36 << iterations, 3)
+    assert np.array_equal(exact, want)
+    fast = ms.scale2x_image_u8(img, iterations)
+    diff = np.abs(fast.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.01, (diff.max(), (diff != 0).mean())
+    # strided input rows (an ROI of a wider image)
+    wide = rng.integers(0, 256, (24, 50, 3), dtype=np.uint8)
+    roi = wide[:, 5:41]
+    out = np.empty_like(want)
+    rc = gpu.lib().w2xc_scale2x_image_u8(ms.handle, roi.ctypes.data, wide.strides[0], 36, 24, out.ctypes.data, out.strides[0],
+                                         iterations, gpu.make_opts(kernel=gpu.KERNEL_DIRECT))
+    assert rc == 0, gpu.last_error()
+    assert np.array_equal(out, orc.scale2x_image_u8(orc.Oracle(scale_layers), np.ascontiguousarray(roi), iterations))

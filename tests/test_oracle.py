@@ -134,3 +134,22 @@ def test_golden_fixtures(oracle_built):
         o = orc.Oracle(layers)
         got = o.convert(g["input"], block=(int(g["block"]), int(g["block"])))
         assert np.array_equal(got, g["output"]), f
+
+
+def test_color_oracle_sanity(oracle_built):
+    """N2 restatement (oracle/w2xc_oracle_color.c): u8 -> YUV -> u8 is the identity on every byte triple sampled,
+    the cubic kernel agrees with an independent implementation (torch bicubic, A = -0.75, half-pixel centres),
+    nearest 2x is a pixel repeat."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    y, u, v = orc.u8_to_yuv(img)
+    assert np.array_equal(orc.yuv_to_u8(y, u, v), img)
+    assert np.allclose(y, (0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2]) / 255.0, atol=1e-6)
+    x = rng.random((9, 11), dtype=np.float32)
+    t = F.interpolate(torch.from_numpy(x)[None, None], scale_factor=2, mode="bicubic", align_corners=False)[0, 0].numpy()
+    assert np.abs(orc.resize2x_cubic(x) - t).max() < 1e-6
+    assert np.array_equal(orc.resize2x_nearest(x), np.repeat(np.repeat(x, 2, 0), 2, 1))
+    const = np.full((5, 6), 0.37, np.float32)
+    assert np.abs(orc.resize2x_cubic(const) - 0.37).max() < 1e-6       # partition of unity incl. clipped borders

@@ -76,6 +76,11 @@ def _load():
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_planes_device": (ci, [vp, ci, fp, cs, cs, ci, ci, fp, cs, cs, vp, C.POINTER(Opts)]),
+        "w2xc_scale2x_image_u8_device": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, vp, C.POINTER(Opts)]),
+        "w2xc_scale2x_image_u8": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
+        "w2xc_resize2x_cubic_device": (ci, [fp, ci, ci, fp, vp]),
+        "w2xc_u8_to_yuv_device": (ci, [fp, cs, ci, ci, fp, fp, fp, vp]),
+        "w2xc_yuv_to_u8_device": (ci, [fp, fp, fp, ci, ci, fp, cs, vp]),
         "w2xc_convert_plane_nn2x": (ci, [vp, fp, cs, ci, ci, fp, cs, C.POINTER(Opts)]),
         "w2xc_convert_plane_nn2x_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_rows_device": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
@@ -233,6 +238,26 @@ class _ModelSet:
         rc = _lib.w2xc_convert_planes_device(self.handle, n_in, C.c_void_p(d_in), in_plane_stride_bytes, in_stride_bytes, w, h,
                                              C.c_void_p(d_out), out_plane_stride_bytes, out_stride_bytes, C.c_void_p(stream),
                                              C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+
+    def scale2x_image_u8(self, img, iterations=1, opts=None):
+        """The CLI's scale phase on an h x w x 3 uint8 image (main.cpp:74-76,126-156,171-172) -> (h<<it) x (w<<it) x 3."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w, ch = img.shape
+        if ch != 3:
+            raise ValueError("want h x w x 3 uint8")
+        out = np.empty((h << iterations, w << iterations, 3), np.uint8)
+        rc = _lib.w2xc_scale2x_image_u8(self.handle, img.ctypes.data, img.strides[0], w, h, out.ctypes.data, out.strides[0],
+                                        iterations, C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+        return out
+
+    def scale2x_image_u8_device(self, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations=1, stream=0, opts=None):
+        rc = _lib.w2xc_scale2x_image_u8_device(self.handle, C.c_void_p(d_in), in_stride_bytes, w, h, C.c_void_p(d_out),
+                                               out_stride_bytes, iterations, C.c_void_p(stream),
+                                               C.byref(opts) if opts is not None else None)
         if rc != OK:
             raise W2xcError(rc, last_error())
 

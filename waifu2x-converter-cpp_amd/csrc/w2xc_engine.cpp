@@ -80,6 +80,8 @@ struct DevCtx {
     std::vector<DevLayer> layers;
     float *ws[2] = {nullptr, nullptr};
     size_t ws_floats[2] = {0, 0};
+    float *aux = nullptr;       // N2: Y/U/V planes of the image pipeline
+    size_t aux_floats = 0;
     std::vector<ProfEvent> pending, pool;
     std::vector<double> layer_ms;
     std::vector<int> layer_launches;
@@ -98,6 +100,7 @@ struct DevCtx {
         }
         for (int i = 0; i < 2; i++)
             if (ws[i]) hipFree(ws[i]);
+        if (aux) hipFree(aux);
         for (auto &e : pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto &e : pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         hipSetDevice(prev);
@@ -783,6 +786,128 @@ int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *co
     rc = body();
     cleanup();
     return rc;
+}
+
+// ---- N2: the scale phase of the CLI on one uint8 image (main.cpp:74-76,126-156,171-172) --------------------
+}  // extern "C"
+
+namespace {
+int scale2x_image_device(w2xc_model *m, DevCtx *c, const unsigned char *d_in, size_t in_stride, int w, int h, unsigned char *d_out,
+                         size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o)
+{
+    // planes: level 0 (w x h) and one ping-pong pair of levels for the iterations
+    size_t need = 0, lvl = (size_t)w * h;
+    for (int i = 0; i <= iterations; i++) { need += 3 * lvl; lvl *= 4; }
+    if (c->aux_floats < need) {
+        if (c->aux) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->aux)); c->aux = nullptr; c->aux_floats = 0; }
+        hipError_t e = hipMalloc((void **)&c->aux, need * sizeof(float));
+        if (e != hipSuccess) return fail(W2XC_ERR_NOMEM, "hipMalloc(%zu MiB) for the image planes failed: %s", (need * 4) >> 20, hipGetErrorString(e));
+        c->aux_floats = need;
+    }
+    float *base = c->aux;
+    int cw = w, ch = h;
+    float *y = base, *u = y + (size_t)cw * ch, *v = u + (size_t)cw * ch;
+    base = v + (size_t)cw * ch;
+    HIP_TRY(w2xc_launch_u8_to_yuv(d_in, in_stride, w, h, y, u, v, st));                                   // :75-76
+    for (int it = 0; it < iterations; it++) {
+        const int nw = cw * 2, nh = ch * 2;
+        float *y2 = base, *u2 = y2 + (size_t)nw * nh, *v2 = u2 + (size_t)nw * nh;
+        base = v2 + (size_t)nw * nh;
+        // Y: INTER_NEAREST 2x folded into layer 1 (:136-140) + convertWithModels (:148)
+        int rc = run_rows(m, c, y, cw, nh, 0, nw, 0, nh, y2, nw, st, o, 1);
+        if (rc) return rc;
+        HIP_TRY(w2xc_launch_resize2x_cubic(u, cw, ch, u2, st));                                            // :144-146
+        HIP_TRY(w2xc_launch_resize2x_cubic(v, cw, ch, v2, st));
+        y = y2; u = u2; v = v2; cw = nw; ch = nh;
+    }
+    HIP_TRY(w2xc_launch_yuv_to_u8(y, u, v, cw, ch, d_out, out_stride, st));                               // :171-172
+    return W2XC_OK;
+}
+
+int check_image_args(const w2xc_model *m, const void *in, size_t in_stride, int w, int h, const void *out, size_t out_stride, int iterations)
+{
+    if (!m || !in || !out) return fail(W2XC_ERR_ARG, "null argument");
+    if (w <= 0 || h <= 0 || iterations < 0 || iterations > 4) return fail(W2XC_ERR_ARG, "bad image size / iteration count");
+    if (in_stride < (size_t)w * 3 || out_stride < ((size_t)w << iterations) * 3) return fail(W2XC_ERR_ARG, "row strides must be >= 3*width bytes");
+    return W2XC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int w2xc_scale2x_image_u8_device(w2xc_model *m, const unsigned char *d_in, size_t in_stride_bytes, int w, int h, unsigned char *d_out,
+                                 size_t out_stride_bytes, int iterations, void *hip_stream, const w2xc_opts *opts)
+{
+    int rc = check_image_args(m, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations);
+    if (rc) return rc;
+    const w2xc_opts o = resolve_opts(opts);
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return scale2x_image_device(m, c, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, (hipStream_t)hip_stream, o);
+}
+
+int w2xc_scale2x_image_u8(w2xc_model *m, const unsigned char *in, size_t in_stride_bytes, int w, int h, unsigned char *out,
+                          size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
+{
+    int rc = check_image_args(m, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations);
+    if (rc) return rc;
+    if (w2xc_device_count() <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
+    const w2xc_opts o = resolve_opts(opts);
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
+    DevCtx *c = nullptr;
+    rc = get_ctx(m, dev, &c);
+    if (rc) return rc;
+    const int W = w << iterations, H = h << iterations;
+    unsigned char *d_in = nullptr, *d_out = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&d_in, (size_t)w * 3 * h));
+        HIP_TRY(hipMalloc((void **)&d_out, (size_t)W * 3 * H));
+        HIP_TRY(hipMemcpy2D(d_in, (size_t)w * 3, in, in_stride_bytes, (size_t)w * 3, h, hipMemcpyHostToDevice));
+        int r;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            r = scale2x_image_device(m, c, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, nullptr, o);
+        }
+        if (r) return r;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy2D(out, out_stride_bytes, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost));
+        return W2XC_OK;
+    };
+    rc = body();
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}
+
+int w2xc_resize2x_cubic_device(const float *d_src, int w, int h, float *d_dst, void *hip_stream)
+{
+    if (!d_src || !d_dst || w <= 0 || h <= 0) return fail(W2XC_ERR_ARG, "bad argument");
+    HIP_TRY(w2xc_launch_resize2x_cubic(d_src, w, h, d_dst, (hipStream_t)hip_stream));
+    return W2XC_OK;
+}
+
+int w2xc_u8_to_yuv_device(const unsigned char *d_in, size_t in_stride_bytes, int w, int h, float *d_y, float *d_u, float *d_v, void *hip_stream)
+{
+    if (!d_in || !d_y || !d_u || !d_v || w <= 0 || h <= 0 || in_stride_bytes < (size_t)w * 3) return fail(W2XC_ERR_ARG, "bad argument");
+    HIP_TRY(w2xc_launch_u8_to_yuv(d_in, in_stride_bytes, w, h, d_y, d_u, d_v, (hipStream_t)hip_stream));
+    return W2XC_OK;
+}
+
+int w2xc_yuv_to_u8_device(const float *d_y, const float *d_u, const float *d_v, int w, int h, unsigned char *d_out, size_t out_stride_bytes,
+                          void *hip_stream)
+{
+    if (!d_out || !d_y || !d_u || !d_v || w <= 0 || h <= 0 || out_stride_bytes < (size_t)w * 3) return fail(W2XC_ERR_ARG, "bad argument");
+    HIP_TRY(w2xc_launch_yuv_to_u8(d_y, d_u, d_v, w, h, d_out, out_stride_bytes, (hipStream_t)hip_stream));
+    return W2XC_OK;
 }
 
 // ---- measurement ----------------------------------------------------------------------------------

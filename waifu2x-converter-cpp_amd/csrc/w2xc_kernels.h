@@ -54,3 +54,8 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
 hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, long long s_cs,
                               float *dst, long long d_rs, long long d_ps, long long d_cs,
                               int h, int w, int c, hipStream_t stream);
+
+// N2 (w2xc_color.hip): colour front/back end and U/V bicubic of the CLI scale loop (main.cpp:74-76,144,171-172)
+hipError_t w2xc_launch_u8_to_yuv(const unsigned char *src, size_t stride, int w, int h, float *y, float *u, float *v, hipStream_t st);
+hipError_t w2xc_launch_yuv_to_u8(const float *y, const float *u, const float *v, int w, int h, unsigned char *dst, size_t stride, hipStream_t st);
+hipError_t w2xc_launch_resize2x_cubic(const float *src, int w, int h, float *dst, hipStream_t st);
