@@ -28,6 +28,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -952,11 +954,16 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     constexpr int NW = WM * WN;
     const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024);
     auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    // > 64 KiB of dynamic LDS needs the opt-in attribute, and function attributes are per DEVICE
+    // (the in-process multi-GPU path launches this kernel on several devices from several threads)
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev < 64) attr_done.fetch_or(1ull << dev);
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
