@@ -152,6 +152,14 @@ int w2xc_scale2x_image_u8_device(w2xc_model *scale_model, const unsigned char *d
                                  const w2xc_opts *opts);
 int w2xc_scale2x_image_u8(w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
                           unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts);
+/* All three processing modes of the CLI (main.cpp:46-48, -m noise | scale | noise_scale) on one uint8 image:
+ * an optional noise model is applied to Y first (main.cpp:83-98), then `iterations` 2x steps with the scale
+ * model.  noise_model or scale_model may be NULL (iterations must be 0 without a scale model). */
+int w2xc_process_image_u8_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in,
+                                 size_t in_stride_bytes, int w, int h, unsigned char *d_out, size_t out_stride_bytes,
+                                 int iterations, void *hip_stream, const w2xc_opts *opts);
+int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes,
+                          int w, int h, unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts);
 /* the building blocks on contiguous float planes (device pointers): main.cpp:144 on one plane, :75-76, :171-172 */
 int w2xc_resize2x_cubic_device(const float *d_src, int w, int h, float *d_dst, void *hip_stream);
 int w2xc_u8_to_yuv_device(const unsigned char *d_in, size_t in_stride_bytes, int w, int h, float *d_y, float *d_u,

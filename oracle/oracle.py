@@ -221,3 +221,14 @@ def scale2x_image_u8(oracle, img, iterations=1):
         y = oracle.convert(resize2x_nearest(y))
         u, v = resize2x_cubic(u), resize2x_cubic(v)
     return yuv_to_u8(y, u, v)
+
+
+def process_image_u8(img, noise_oracle=None, scale_oracle=None, iterations=0):
+    """noise (main.cpp:83-98) then `iterations` 2x steps (main.cpp:126-156) on a uint8 image."""
+    y, u, v = u8_to_yuv(img)
+    if noise_oracle is not None:
+        y = noise_oracle.convert(y)
+    for _ in range(iterations):
+        y = scale_oracle.convert(resize2x_nearest(y))
+        u, v = resize2x_cubic(u), resize2x_cubic(v)
+    return yuv_to_u8(y, u, v)

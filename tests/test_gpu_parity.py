@@ -433,3 +433,19 @@ def test_scale2x_image_u8_pipeline(gpu, scale_layers, iterations):
                                          iterations, gpu.make_opts(kernel=gpu.KERNEL_DIRECT))
     assert rc == 0, gpu.last_error()
     assert np.array_equal(out, orc.scale2x_image_u8(orc.Oracle(scale_layers), np.ascontiguousarray(roi), iterations))
+
+
+@pytest.mark.parametrize("mode", ["noise", "noise_scale"])
+def test_process_image_modes(gpu, noise1_layers, scale_layers, mode):
+    """-m noise and -m noise_scale of the CLI (main.cpp:83-98 then :126-156) on a uint8 image"""
+    mn, msc = gpu._ModelSet.from_layers(noise1_layers), gpu._ModelSet.from_layers(scale_layers)
+    img = np.random.default_rng(9).integers(0, 256, (20, 28, 3), dtype=np.uint8)
+    it = 1 if mode == "noise_scale" else 0
+    want = orc.process_image_u8(img, orc.Oracle(noise1_layers), orc.Oracle(scale_layers) if it else None, it)
+    got = gpu.process_image_u8(img, mn, msc if it else None, it, direct(gpu))
+    assert np.array_equal(got, want)
+    fast = gpu.process_image_u8(img, mn, msc if it else None, it)
+    assert np.abs(fast.astype(np.int16) - want.astype(np.int16)).max() <= 1
+    with pytest.raises(gpu.W2xcError) as e:
+        gpu.process_image_u8(img, None, None, 0)
+    assert e.value.code == gpu.ERR_ARG

@@ -76,6 +76,8 @@ def _load():
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_planes_device": (ci, [vp, ci, fp, cs, cs, ci, ci, fp, cs, cs, vp, C.POINTER(Opts)]),
+        "w2xc_process_image_u8_device": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, vp, C.POINTER(Opts)]),
+        "w2xc_process_image_u8": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_scale2x_image_u8_device": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, vp, C.POINTER(Opts)]),
         "w2xc_scale2x_image_u8": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_resize2x_cubic_device": (ci, [fp, ci, ci, fp, vp]),
@@ -436,3 +438,17 @@ def shard_view(plane_h, row_begin, row_end, n_layers):
     """Input rows [y0, y1) a shard needs: its rows plus an n_layers halo, clipped to the plane
     (the 2*nModel overlap of the reference's block split, convertRoutine.cpp:100-131)."""
     return max(0, row_begin - n_layers), min(plane_h, row_end + n_layers)
+
+
+def process_image_u8(img, noise=None, scale=None, iterations=0, opts=None):
+    """The CLI's processing modes on an h x w x 3 uint8 image (main.cpp -m noise | scale | noise_scale):
+    `noise` / `scale` are _ModelSet objects (either may be None)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+    out = np.empty((h << iterations, w << iterations, 3), np.uint8)
+    rc = _lib.w2xc_process_image_u8(noise.handle if noise else None, scale.handle if scale else None, img.ctypes.data,
+                                    img.strides[0], w, h, out.ctypes.data, out.strides[0], iterations,
+                                    C.byref(opts) if opts is not None else None)
+    if rc != OK:
+        raise W2xcError(rc, last_error())
+    return out

@@ -792,12 +792,16 @@ int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *co
 }  // extern "C"
 
 namespace {
-int scale2x_image_device(w2xc_model *m, DevCtx *c, const unsigned char *d_in, size_t in_stride, int w, int h, unsigned char *d_out,
-                         size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o)
+// noise (optional, main.cpp:83-98) then `iterations` 2x scale steps (optional model, main.cpp:126-156).
+// `c` is the context that owns the plane buffer (the scale model's when present, else the noise model's);
+// cn / cs are the contexts of the two models (locked by the caller).
+int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs, const unsigned char *d_in, size_t in_stride, int w,
+                         int h, unsigned char *d_out, size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o)
 {
-    // planes: level 0 (w x h) and one ping-pong pair of levels for the iterations
-    size_t need = 0, lvl = (size_t)w * h;
-    for (int i = 0; i <= iterations; i++) { need += 3 * lvl; lvl *= 4; }
+    DevCtx *c = cs ? cs : cn;
+    // planes: level 0 (w x h) twice when a noise pass needs a second Y, then one level per iteration
+    size_t need = 4 * (size_t)w * h, lvl = (size_t)w * h;
+    for (int i = 1; i <= iterations; i++) { lvl *= 4; need += 3 * lvl; }
     if (c->aux_floats < need) {
         if (c->aux) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->aux)); c->aux = nullptr; c->aux_floats = 0; }
         hipError_t e = hipMalloc((void **)&c->aux, need * sizeof(float));
@@ -806,21 +810,48 @@ int scale2x_image_device(w2xc_model *m, DevCtx *c, const unsigned char *d_in, si
     }
     float *base = c->aux;
     int cw = w, ch = h;
-    float *y = base, *u = y + (size_t)cw * ch, *v = u + (size_t)cw * ch;
-    base = v + (size_t)cw * ch;
+    float *y = base, *u = y + (size_t)cw * ch, *v = u + (size_t)cw * ch, *yn = v + (size_t)cw * ch;
+    base = yn + (size_t)cw * ch;
     HIP_TRY(w2xc_launch_u8_to_yuv(d_in, in_stride, w, h, y, u, v, st));                                   // :75-76
+    if (mn) {                                                                                             // :91-98
+        int rc = run_rows(mn, cn, y, cw, ch, 0, cw, 0, ch, yn, cw, st, o, 0);
+        if (rc) return rc;
+        y = yn;
+    }
     for (int it = 0; it < iterations; it++) {
         const int nw = cw * 2, nh = ch * 2;
         float *y2 = base, *u2 = y2 + (size_t)nw * nh, *v2 = u2 + (size_t)nw * nh;
         base = v2 + (size_t)nw * nh;
         // Y: INTER_NEAREST 2x folded into layer 1 (:136-140) + convertWithModels (:148)
-        int rc = run_rows(m, c, y, cw, nh, 0, nw, 0, nh, y2, nw, st, o, 1);
+        int rc = run_rows(msc, cs, y, cw, nh, 0, nw, 0, nh, y2, nw, st, o, 1);
         if (rc) return rc;
         HIP_TRY(w2xc_launch_resize2x_cubic(u, cw, ch, u2, st));                                            // :144-146
         HIP_TRY(w2xc_launch_resize2x_cubic(v, cw, ch, v2, st));
         y = y2; u = u2; v = v2; cw = nw; ch = nh;
     }
     HIP_TRY(w2xc_launch_yuv_to_u8(y, u, v, cw, ch, d_out, out_stride, st));                               // :171-172
+    return W2XC_OK;
+}
+
+// resolve device + contexts of the (up to two) models and run the pipeline under their locks
+int process_image_locked(w2xc_model *mn, w2xc_model *msc, const unsigned char *d_in, size_t in_stride, int w, int h, unsigned char *d_out,
+                         size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o, int dev)
+{
+    DevCtx *cn = nullptr, *cs = nullptr;
+    int rc;
+    if (mn && (rc = get_ctx(mn, dev, &cn))) return rc;
+    if (msc && (rc = get_ctx(msc, dev, &cs))) return rc;
+    std::unique_lock<std::mutex> l1, l2;
+    if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
+    if (cs && cs != cn) l2 = std::unique_lock<std::mutex>(cs->mu);
+    return process_image_device(mn, cn, msc, cs, d_in, in_stride, w, h, d_out, out_stride, iterations, st, o);
+}
+
+int check_process_args(const w2xc_model *mn, const w2xc_model *msc, int iterations)
+{
+    if (!mn && !msc) return fail(W2XC_ERR_ARG, "need a noise model, a scale model or both");
+    if (iterations > 0 && !msc) return fail(W2XC_ERR_ARG, "scale iterations need a scale model");
+    if (!mn && iterations == 0) return fail(W2XC_ERR_ARG, "nothing to do (no noise model, 0 iterations)");
     return W2XC_OK;
 }
 
@@ -835,27 +866,29 @@ int check_image_args(const w2xc_model *m, const void *in, size_t in_stride, int 
 
 extern "C" {
 
-int w2xc_scale2x_image_u8_device(w2xc_model *m, const unsigned char *d_in, size_t in_stride_bytes, int w, int h, unsigned char *d_out,
-                                 size_t out_stride_bytes, int iterations, void *hip_stream, const w2xc_opts *opts)
+int w2xc_process_image_u8_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in, size_t in_stride_bytes,
+                                 int w, int h, unsigned char *d_out, size_t out_stride_bytes, int iterations, void *hip_stream,
+                                 const w2xc_opts *opts)
 {
-    int rc = check_image_args(m, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations);
+    int rc = check_process_args(noise_model, scale_model, iterations);
+    if (rc) return rc;
+    rc = check_image_args(noise_model ? noise_model : scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations);
     if (rc) return rc;
     const w2xc_opts o = resolve_opts(opts);
     int dev = o.device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);
     if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
-    DevCtx *c = nullptr;
-    rc = get_ctx(m, dev, &c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(c->mu);
-    return scale2x_image_device(m, c, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, (hipStream_t)hip_stream, o);
+    return process_image_locked(noise_model, scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations,
+                                (hipStream_t)hip_stream, o, dev);
 }
 
-int w2xc_scale2x_image_u8(w2xc_model *m, const unsigned char *in, size_t in_stride_bytes, int w, int h, unsigned char *out,
-                          size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
+int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
+                          unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
 {
-    int rc = check_image_args(m, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations);
+    int rc = check_process_args(noise_model, scale_model, iterations);
+    if (rc) return rc;
+    rc = check_image_args(noise_model ? noise_model : scale_model, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations);
     if (rc) return rc;
     if (w2xc_device_count() <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
     const w2xc_opts o = resolve_opts(opts);
@@ -863,20 +896,13 @@ int w2xc_scale2x_image_u8(w2xc_model *m, const unsigned char *in, size_t in_stri
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);
     if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
-    DevCtx *c = nullptr;
-    rc = get_ctx(m, dev, &c);
-    if (rc) return rc;
     const int W = w << iterations, H = h << iterations;
     unsigned char *d_in = nullptr, *d_out = nullptr;
     auto body = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&d_in, (size_t)w * 3 * h));
         HIP_TRY(hipMalloc((void **)&d_out, (size_t)W * 3 * H));
         HIP_TRY(hipMemcpy2D(d_in, (size_t)w * 3, in, in_stride_bytes, (size_t)w * 3, h, hipMemcpyHostToDevice));
-        int r;
-        {
-            std::lock_guard<std::mutex> lk(c->mu);
-            r = scale2x_image_device(m, c, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, nullptr, o);
-        }
+        int r = process_image_locked(noise_model, scale_model, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, nullptr, o, dev);
         if (r) return r;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy2D(out, out_stride_bytes, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost));
@@ -886,6 +912,18 @@ int w2xc_scale2x_image_u8(w2xc_model *m, const unsigned char *in, size_t in_stri
     hipFree(d_in);
     hipFree(d_out);
     return rc;
+}
+
+int w2xc_scale2x_image_u8_device(w2xc_model *m, const unsigned char *d_in, size_t in_stride_bytes, int w, int h, unsigned char *d_out,
+                                 size_t out_stride_bytes, int iterations, void *hip_stream, const w2xc_opts *opts)
+{
+    return w2xc_process_image_u8_device(nullptr, m, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, hip_stream, opts);
+}
+
+int w2xc_scale2x_image_u8(w2xc_model *m, const unsigned char *in, size_t in_stride_bytes, int w, int h, unsigned char *out,
+                          size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
+{
+    return w2xc_process_image_u8(nullptr, m, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations, opts);
 }
 
 int w2xc_resize2x_cubic_device(const float *d_src, int w, int h, float *d_dst, void *hip_stream)
