@@ -160,6 +160,16 @@ int w2xc_process_image_u8_device(w2xc_model *noise_model, w2xc_model *scale_mode
                                  int iterations, void *hip_stream, const w2xc_opts *opts);
 int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes,
                           int w, int h, unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts);
+/* ... plus the final INTER_LINEAR shrink the CLI applies for scale ratios that are not powers of two
+ * (main.cpp:107-114,158-167): shrink_ratio in (0,1) resizes the float YUV image to
+ * int((w << iterations) * shrink_ratio) x int((h << iterations) * shrink_ratio) before the conversion back to
+ * uint8; 0 = no shrink. */
+int w2xc_process_image_u8_ex_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in,
+                                    size_t in_stride_bytes, int w, int h, unsigned char *d_out, size_t out_stride_bytes,
+                                    int iterations, double shrink_ratio, void *hip_stream, const w2xc_opts *opts);
+int w2xc_process_image_u8_ex(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes,
+                             int w, int h, unsigned char *out, size_t out_stride_bytes, int iterations, double shrink_ratio,
+                             const w2xc_opts *opts);
 /* the building blocks on contiguous float planes (device pointers): main.cpp:144 on one plane, :75-76, :171-172 */
 int w2xc_resize2x_cubic_device(const float *d_src, int w, int h, float *d_dst, void *hip_stream);
 int w2xc_u8_to_yuv_device(const unsigned char *d_in, size_t in_stride_bytes, int w, int h, float *d_y, float *d_u,

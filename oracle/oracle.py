@@ -223,12 +223,25 @@ def scale2x_image_u8(oracle, img, iterations=1):
     return yuv_to_u8(y, u, v)
 
 
-def process_image_u8(img, noise_oracle=None, scale_oracle=None, iterations=0):
-    """noise (main.cpp:83-98) then `iterations` 2x steps (main.cpp:126-156) on a uint8 image."""
+def resize_linear(plane, dw, dh):
+    """main.cpp:158-167 on one plane: cv::resize(..., INTER_LINEAR)."""
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    h, w = plane.shape
+    out = np.empty((dh, dw), np.float32)
+    _color_lib().w2xc_oracle_resize_linear(C.c_void_p(plane.ctypes.data), w, h, C.c_void_p(out.ctypes.data), dw, dh)
+    return out
+
+
+def process_image_u8(img, noise_oracle=None, scale_oracle=None, iterations=0, shrink_ratio=0.0):
+    """noise (main.cpp:83-98), `iterations` 2x steps (:126-156), optional INTER_LINEAR shrink (:158-167)."""
     y, u, v = u8_to_yuv(img)
     if noise_oracle is not None:
         y = noise_oracle.convert(y)
     for _ in range(iterations):
         y = scale_oracle.convert(resize2x_nearest(y))
         u, v = resize2x_cubic(u), resize2x_cubic(v)
+    if shrink_ratio:
+        h, w = y.shape
+        dw, dh = int(float(w * shrink_ratio)), int(float(h * shrink_ratio))
+        y, u, v = (resize_linear(p, dw, dh) for p in (y, u, v))
     return yuv_to_u8(y, u, v)

@@ -123,3 +123,44 @@ void w2xc_oracle_resize2x_nearest(const float *src, int w, int h, float *dst)
     for (int y = 0; y < 2 * h; y++)
         for (int x = 0; x < 2 * w; x++) dst[(size_t)y * 2 * w + x] = src[(size_t)(y >> 1) * w + (x >> 1)];
 }
+
+/* main.cpp:158-167 on one plane: cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR) for CV_32F.
+ * OpenCV semantics: fx = (dx + 0.5) * (sw/dw) - 0.5; sx = floor(fx); fx -= sx; sx < 0 -> (sx, fx) = (0, 0);
+ * sx >= sw-1 -> (sw-1, 0); weights (1-fx, fx); horizontal pass to float rows, then vertical pass; each a
+ * two-term left-to-right sum.  PARITY UNPINNED (OpenCV absent). */
+void w2xc_oracle_resize_linear(const float *src, int sw, int sh, float *dst, int dw, int dh)
+{
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    float *tmp = (float *)malloc((size_t)dw * sh * sizeof(float));
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+        const float a0 = 1.f - fx, a1 = fx;
+        for (int r = 0; r < sh; r++) {
+            const float *S = src + (size_t)r * sw;
+            float a = S[sx] * a0;
+            a = a + S[sx1] * a1;
+            tmp[(size_t)r * dw + dx] = a;
+        }
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+        const float b0 = 1.f - fy, b1 = fy;
+        const float *R0 = tmp + (size_t)sy * dw, *R1 = tmp + (size_t)sy1 * dw;
+        for (int x = 0; x < dw; x++) {
+            float a = R0[x] * b0;
+            a = a + R1[x] * b1;
+            dst[(size_t)dy * dw + x] = a;
+        }
+    }
+    free(tmp);
+}

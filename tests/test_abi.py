@@ -163,3 +163,23 @@ def test_arbitrary_model_lists_get_their_own_container(w2xc):
     sub = w2xc._set_of(models[:2])
     assert sub is not a and sub.n_layers == 2 and sub.planes(1) == (4, 4)
     assert np.array_equal(sub.layer_arrays(1)[2], a.layer_arrays(1)[2])
+
+
+def test_cli_shell_logic():
+    """N4 (tools/w2xc_cli.py): ratio -> (2x iterations, shrink) exactly like main.cpp:107-114, the automatic
+    output name of main.cpp:173-189, and the reference's flag set (main.cpp:26-60)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("w2xc_cli", os.path.join(ROOT, "tools", "w2xc_cli.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    assert cli.plan_scale(2.0) == (1, 0.0)
+    assert cli.plan_scale(4.0) == (2, 0.0)
+    assert cli.plan_scale(1.0) == (0, 0.0)
+    assert cli.plan_scale(1.5) == (1, 0.75)
+    assert cli.plan_scale(3.0) == (2, 0.75)
+    assert cli.plan_scale(2.5) == (2, 0.625)
+    assert cli.auto_output_name("/x/pic.v1.jpg", "noise_scale", 2, 2.0) == "/x/pic.v1(noise_scale)(Level2)(x2.000000).png"
+    assert cli.auto_output_name("a.png", "scale", 1, 1.5) == "a(scale)(x1.500000).png"
+    assert cli.auto_output_name("a.png", "noise", 1, 2.0) == "a(noise)(Level1).png"
+    a = cli.build_parser().parse_args(["-i", "in.png"])
+    assert (a.output_file, a.mode, a.noise_level, a.scale_ratio, a.model_dir, a.jobs) == ("(auto)", "noise_scale", 1, 2.0, "models", 4)

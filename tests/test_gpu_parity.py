@@ -449,3 +449,39 @@ def test_process_image_modes(gpu, noise1_layers, scale_layers, mode):
     with pytest.raises(gpu.W2xcError) as e:
         gpu.process_image_u8(img, None, None, 0)
     assert e.value.code == gpu.ERR_ARG
+
+
+@pytest.mark.parametrize("ratio", [1.5, 3.0])
+def test_process_image_shrink(gpu, scale_layers, ratio):
+    """--scale_ratio that is not a power of two: iter = ceil(log2 r) 2x steps, then INTER_LINEAR shrink by
+    r / 2^iter (main.cpp:107-114,158-167)"""
+    import math
+    msc = gpu._ModelSet.from_layers(scale_layers)
+    img = np.random.default_rng(3).integers(0, 256, (18, 26, 3), dtype=np.uint8)
+    it = int(math.ceil(math.log2(ratio)))
+    shrink = ratio / 2.0 ** it
+    want = orc.process_image_u8(img, None, orc.Oracle(scale_layers), it, shrink)
+    got = gpu.process_image_u8(img, None, msc, it, direct(gpu), shrink)
+    assert got.shape == want.shape == (int(float((18 << it) * shrink)), int(float((26 << it) * shrink)), 3)
+    assert np.array_equal(got, want)
+
+
+def test_cli_shell_end_to_end(gpu, models_dir, tmp_path):
+    """N4: tools/w2xc_cli.py -m noise_scale --scale_ratio 1.5 on a PNG vs the CPU restatement of main.cpp"""
+    import subprocess, sys
+    from PIL import Image
+    from conftest import ROOT
+    rgb = np.random.default_rng(12).integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    src = tmp_path / "in.png"
+    Image.fromarray(rgb).save(src)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "w2xc_cli.py"), "-i", str(src), "-m", "noise_scale",
+                        "--noise_level", "2", "--scale_ratio", "1.5", "--model_dir", models_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out_path = tmp_path / "in(noise_scale)(Level2)(x1.500000).png"
+    assert out_path.exists() and "process successfully done!" in r.stdout
+    got = np.asarray(Image.open(out_path))
+    no = orc.Oracle.from_json(os.path.join(models_dir, "noise2_model.json"))
+    so = orc.Oracle.from_json(os.path.join(models_dir, "scale2.0x_model.json"))
+    want = orc.process_image_u8(np.ascontiguousarray(rgb[:, :, ::-1]), no, so, 1, 0.75)[:, :, ::-1]
+    assert got.shape == want.shape == (30, 45, 3)
+    assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1

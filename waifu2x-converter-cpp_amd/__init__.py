@@ -76,6 +76,8 @@ def _load():
         "w2xc_convert_plane": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_convert_plane_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_convert_planes_device": (ci, [vp, ci, fp, cs, cs, ci, ci, fp, cs, cs, vp, C.POINTER(Opts)]),
+        "w2xc_process_image_u8_ex_device": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, C.c_double, vp, C.POINTER(Opts)]),
+        "w2xc_process_image_u8_ex": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, C.c_double, C.POINTER(Opts)]),
         "w2xc_process_image_u8_device": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, vp, C.POINTER(Opts)]),
         "w2xc_process_image_u8": (ci, [vp, vp, fp, cs, ci, ci, fp, cs, ci, C.POINTER(Opts)]),
         "w2xc_scale2x_image_u8_device": (ci, [vp, fp, cs, ci, ci, fp, cs, ci, vp, C.POINTER(Opts)]),
@@ -440,15 +442,19 @@ def shard_view(plane_h, row_begin, row_end, n_layers):
     return max(0, row_begin - n_layers), min(plane_h, row_end + n_layers)
 
 
-def process_image_u8(img, noise=None, scale=None, iterations=0, opts=None):
+def process_image_u8(img, noise=None, scale=None, iterations=0, opts=None, shrink_ratio=0.0):
     """The CLI's processing modes on an h x w x 3 uint8 image (main.cpp -m noise | scale | noise_scale):
-    `noise` / `scale` are _ModelSet objects (either may be None)."""
+    `noise` / `scale` are _ModelSet objects (either may be None); shrink_ratio = the final INTER_LINEAR shrink
+    of main.cpp:158-167 (0 = none)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w, _ = img.shape
-    out = np.empty((h << iterations, w << iterations, 3), np.uint8)
-    rc = _lib.w2xc_process_image_u8(noise.handle if noise else None, scale.handle if scale else None, img.ctypes.data,
-                                    img.strides[0], w, h, out.ctypes.data, out.strides[0], iterations,
-                                    C.byref(opts) if opts is not None else None)
+    fh, fw = h << iterations, w << iterations
+    if shrink_ratio:
+        fw, fh = int(float(fw * shrink_ratio)), int(float(fh * shrink_ratio))
+    out = np.empty((fh, fw, 3), np.uint8)
+    rc = _lib.w2xc_process_image_u8_ex(noise.handle if noise else None, scale.handle if scale else None, img.ctypes.data,
+                                       img.strides[0], w, h, out.ctypes.data, out.strides[0], iterations, float(shrink_ratio),
+                                       C.byref(opts) if opts is not None else None)
     if rc != OK:
         raise W2xcError(rc, last_error())
     return out

@@ -85,6 +85,34 @@ __global__ void __launch_bounds__(256) k_resize2x_cubic(const float *src, int w,
     }
 }
 
+// main.cpp:158-167 on one plane: cv::resize(Size(dw, dh), INTER_LINEAR): half-pixel centres, the two taps
+// clipped to the image, horizontal pass to float then vertical pass (no antialiasing, like OpenCV).
+__global__ void __launch_bounds__(256) k_resize_linear(const float *src, int sw, int sh, float *dst, int dw, int dh, double scale_x, double scale_y)
+{
+    const long long total = (long long)dw * dh;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int dy = (int)(q / dw), dx = (int)(q - (long long)dy * dw);
+        float fx = (float)((dx + 0.5) * scale_x - 0.5), fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        fx -= sx;
+        fy -= sy;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1, sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        const float *R0 = src + (long long)sy * sw, *R1 = src + (long long)sy1 * sw;
+        float h0 = R0[sx] * a0;
+        h0 = h0 + R0[sx1] * a1;
+        float h1 = R1[sx] * a0;
+        h1 = h1 + R1[sx1] * a1;
+        float a = h0 * b0;
+        a = a + h1 * b1;
+        dst[q] = a;
+    }
+}
+
 static unsigned grid_for(long long total)
 {
     long long b = (total + 255) / 256;
@@ -104,5 +132,11 @@ hipError_t w2xc_launch_yuv_to_u8(const float *y, const float *u, const float *v,
 hipError_t w2xc_launch_resize2x_cubic(const float *src, int w, int h, float *dst, hipStream_t st)
 {
     hipLaunchKernelGGL(k_resize2x_cubic, dim3(grid_for(4LL * w * h)), dim3(256), 0, st, src, w, h, dst);
+    return hipGetLastError();
+}
+hipError_t w2xc_launch_resize_linear(const float *src, int sw, int sh, float *dst, int dw, int dh, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_resize_linear, dim3(grid_for((long long)dw * dh)), dim3(256), 0, st, src, sw, sh, dst, dw, dh,
+                       (double)sw / dw, (double)sh / dh);
     return hipGetLastError();
 }

@@ -795,13 +795,27 @@ namespace {
 // noise (optional, main.cpp:83-98) then `iterations` 2x scale steps (optional model, main.cpp:126-156).
 // `c` is the context that owns the plane buffer (the scale model's when present, else the noise model's);
 // cn / cs are the contexts of the two models (locked by the caller).
+// final size of the pipeline: (w << iterations) x (h << iterations), then the optional shrink of main.cpp:158-167
+void final_size(int w, int h, int iterations, double shrink, int *fw, int *fh)
+{
+    *fw = w << iterations;
+    *fh = h << iterations;
+    if (shrink > 0.0) {
+        *fw = static_cast<int>(static_cast<double>(*fw * shrink));   // :160-165
+        *fh = static_cast<int>(static_cast<double>(*fh * shrink));
+    }
+}
+
 int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs, const unsigned char *d_in, size_t in_stride, int w,
-                         int h, unsigned char *d_out, size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o)
+                         int h, unsigned char *d_out, size_t out_stride, int iterations, double shrink, hipStream_t st, const w2xc_opts &o)
 {
     DevCtx *c = cs ? cs : cn;
     // planes: level 0 (w x h) twice when a noise pass needs a second Y, then one level per iteration
     size_t need = 4 * (size_t)w * h, lvl = (size_t)w * h;
     for (int i = 1; i <= iterations; i++) { lvl *= 4; need += 3 * lvl; }
+    int fw, fh;
+    final_size(w, h, iterations, shrink, &fw, &fh);
+    if (shrink > 0.0) need += 3 * (size_t)fw * fh;
     if (c->aux_floats < need) {
         if (c->aux) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->aux)); c->aux = nullptr; c->aux_floats = 0; }
         hipError_t e = hipMalloc((void **)&c->aux, need * sizeof(float));
@@ -829,13 +843,20 @@ int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs
         HIP_TRY(w2xc_launch_resize2x_cubic(v, cw, ch, v2, st));
         y = y2; u = u2; v = v2; cw = nw; ch = nh;
     }
+    if (shrink > 0.0) {                                                                                   // :158-167
+        float *ys = base, *us = ys + (size_t)fw * fh, *vs = us + (size_t)fw * fh;
+        HIP_TRY(w2xc_launch_resize_linear(y, cw, ch, ys, fw, fh, st));
+        HIP_TRY(w2xc_launch_resize_linear(u, cw, ch, us, fw, fh, st));
+        HIP_TRY(w2xc_launch_resize_linear(v, cw, ch, vs, fw, fh, st));
+        y = ys; u = us; v = vs; cw = fw; ch = fh;
+    }
     HIP_TRY(w2xc_launch_yuv_to_u8(y, u, v, cw, ch, d_out, out_stride, st));                               // :171-172
     return W2XC_OK;
 }
 
 // resolve device + contexts of the (up to two) models and run the pipeline under their locks
 int process_image_locked(w2xc_model *mn, w2xc_model *msc, const unsigned char *d_in, size_t in_stride, int w, int h, unsigned char *d_out,
-                         size_t out_stride, int iterations, hipStream_t st, const w2xc_opts &o, int dev)
+                         size_t out_stride, int iterations, double shrink, hipStream_t st, const w2xc_opts &o, int dev)
 {
     DevCtx *cn = nullptr, *cs = nullptr;
     int rc;
@@ -844,7 +865,7 @@ int process_image_locked(w2xc_model *mn, w2xc_model *msc, const unsigned char *d
     std::unique_lock<std::mutex> l1, l2;
     if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
     if (cs && cs != cn) l2 = std::unique_lock<std::mutex>(cs->mu);
-    return process_image_device(mn, cn, msc, cs, d_in, in_stride, w, h, d_out, out_stride, iterations, st, o);
+    return process_image_device(mn, cn, msc, cs, d_in, in_stride, w, h, d_out, out_stride, iterations, shrink, st, o);
 }
 
 int check_process_args(const w2xc_model *mn, const w2xc_model *msc, int iterations)
@@ -855,40 +876,53 @@ int check_process_args(const w2xc_model *mn, const w2xc_model *msc, int iteratio
     return W2XC_OK;
 }
 
-int check_image_args(const w2xc_model *m, const void *in, size_t in_stride, int w, int h, const void *out, size_t out_stride, int iterations)
+int check_image_args(const w2xc_model *m, const void *in, size_t in_stride, int w, int h, const void *out, size_t out_stride, int iterations,
+                     double shrink = 0.0)
 {
     if (!m || !in || !out) return fail(W2XC_ERR_ARG, "null argument");
     if (w <= 0 || h <= 0 || iterations < 0 || iterations > 4) return fail(W2XC_ERR_ARG, "bad image size / iteration count");
-    if (in_stride < (size_t)w * 3 || out_stride < ((size_t)w << iterations) * 3) return fail(W2XC_ERR_ARG, "row strides must be >= 3*width bytes");
+    if (shrink < 0.0 || shrink >= 1.0) return fail(W2XC_ERR_ARG, "shrink_ratio must be 0 (none) or in (0,1)");
+    int fw, fh;
+    final_size(w, h, iterations, shrink, &fw, &fh);
+    if (fw < 1 || fh < 1) return fail(W2XC_ERR_ARG, "shrink_ratio leaves an empty image");
+    if (in_stride < (size_t)w * 3 || out_stride < (size_t)fw * 3) return fail(W2XC_ERR_ARG, "row strides must be >= 3*width bytes");
     return W2XC_OK;
 }
 }  // namespace
 
 extern "C" {
 
-int w2xc_process_image_u8_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in, size_t in_stride_bytes,
-                                 int w, int h, unsigned char *d_out, size_t out_stride_bytes, int iterations, void *hip_stream,
-                                 const w2xc_opts *opts)
+int w2xc_process_image_u8_ex_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in, size_t in_stride_bytes,
+                                    int w, int h, unsigned char *d_out, size_t out_stride_bytes, int iterations, double shrink_ratio,
+                                    void *hip_stream, const w2xc_opts *opts)
 {
     int rc = check_process_args(noise_model, scale_model, iterations);
     if (rc) return rc;
-    rc = check_image_args(noise_model ? noise_model : scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations);
+    rc = check_image_args(noise_model ? noise_model : scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, shrink_ratio);
     if (rc) return rc;
     const w2xc_opts o = resolve_opts(opts);
     int dev = o.device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);
     if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
-    return process_image_locked(noise_model, scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations,
+    return process_image_locked(noise_model, scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, shrink_ratio,
                                 (hipStream_t)hip_stream, o, dev);
 }
 
-int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
-                          unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
+int w2xc_process_image_u8_device(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *d_in, size_t in_stride_bytes,
+                                 int w, int h, unsigned char *d_out, size_t out_stride_bytes, int iterations, void *hip_stream,
+                                 const w2xc_opts *opts)
+{
+    return w2xc_process_image_u8_ex_device(noise_model, scale_model, d_in, in_stride_bytes, w, h, d_out, out_stride_bytes, iterations, 0.0,
+                                           hip_stream, opts);
+}
+
+int w2xc_process_image_u8_ex(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
+                             unsigned char *out, size_t out_stride_bytes, int iterations, double shrink_ratio, const w2xc_opts *opts)
 {
     int rc = check_process_args(noise_model, scale_model, iterations);
     if (rc) return rc;
-    rc = check_image_args(noise_model ? noise_model : scale_model, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations);
+    rc = check_image_args(noise_model ? noise_model : scale_model, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations, shrink_ratio);
     if (rc) return rc;
     if (w2xc_device_count() <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
     const w2xc_opts o = resolve_opts(opts);
@@ -896,13 +930,15 @@ int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, cons
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);
     if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
-    const int W = w << iterations, H = h << iterations;
+    int W, H;
+    final_size(w, h, iterations, shrink_ratio, &W, &H);
     unsigned char *d_in = nullptr, *d_out = nullptr;
     auto body = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&d_in, (size_t)w * 3 * h));
         HIP_TRY(hipMalloc((void **)&d_out, (size_t)W * 3 * H));
         HIP_TRY(hipMemcpy2D(d_in, (size_t)w * 3, in, in_stride_bytes, (size_t)w * 3, h, hipMemcpyHostToDevice));
-        int r = process_image_locked(noise_model, scale_model, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, nullptr, o, dev);
+        int r = process_image_locked(noise_model, scale_model, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, shrink_ratio,
+                                     nullptr, o, dev);
         if (r) return r;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy2D(out, out_stride_bytes, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost));
@@ -912,6 +948,12 @@ int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, cons
     hipFree(d_in);
     hipFree(d_out);
     return rc;
+}
+
+int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,
+                          unsigned char *out, size_t out_stride_bytes, int iterations, const w2xc_opts *opts)
+{
+    return w2xc_process_image_u8_ex(noise_model, scale_model, in, in_stride_bytes, w, h, out, out_stride_bytes, iterations, 0.0, opts);
 }
 
 int w2xc_scale2x_image_u8_device(w2xc_model *m, const unsigned char *d_in, size_t in_stride_bytes, int w, int h, unsigned char *d_out,

@@ -59,3 +59,4 @@ hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, 
 hipError_t w2xc_launch_u8_to_yuv(const unsigned char *src, size_t stride, int w, int h, float *y, float *u, float *v, hipStream_t st);
 hipError_t w2xc_launch_yuv_to_u8(const float *y, const float *u, const float *v, int w, int h, unsigned char *dst, size_t stride, hipStream_t st);
 hipError_t w2xc_launch_resize2x_cubic(const float *src, int w, int h, float *dst, hipStream_t st);
+hipError_t w2xc_launch_resize_linear(const float *src, int sw, int sh, float *dst, int dw, int dh, hipStream_t st);
