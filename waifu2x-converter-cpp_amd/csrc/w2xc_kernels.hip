@@ -322,9 +322,26 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 
     // ---- per-lane DMA source offsets of the A halo tile (16-byte units), piece jj of this wave ----
     const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
-    unsigned goff[APW];
+    // goff[jj] = lofs[jj] + (tile origin) for tiles whose halo needs no clamping (all but the border tiles):
+    // lofs is tile-independent, so the per-tile bookkeeping is APW adds instead of ~20 VALU per piece.
+    unsigned goff[APW], lofs[APW];
+#pragma unroll
+    for (int jj = 0; jj < APW; jj++) {
+        const int s = (jj * NW + wave) * 64 + lane;
+        int p = s >> 3;
+        p = p < NPIX ? p : NPIX - 1;
+        const int py = p / HW, px = p - py * HW;
+        lofs[jj] = (unsigned)(((long long)py * d.in_rs + (long long)px * CIN) >> 2) + ((s & 7) ^ ((p >> 1) & 7));
+    }
     auto tile_offsets = [&](int t) {
         const int ty_ = t / tiles_x, tx_ = t - ty_ * tiles_x;
+        const int y0 = ty_ * ROWS + d.off_y, x0 = tx_ * 32 + d.off_x;
+        if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
+            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * CIN) >> 2);
+#pragma unroll
+            for (int jj = 0; jj < APW; jj++) goff[jj] = lofs[jj] + base;
+            return;
+        }
 #pragma unroll
         for (int jj = 0; jj < APW; jj++) {
             const int s = (jj * NW + wave) * 64 + lane;           // 16-byte slot in the A buffer
@@ -332,8 +349,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
             p = p < NPIX ? p : NPIX - 1;                           // slots past the tile re-read its last pixel
             const int q = (s & 7) ^ ((p >> 1) & 7);                // chunk stored at this position
             const int py = p / HW, px = p - py * HW;
-            const int gy = clampi(ty_ * ROWS + py + d.off_y, 0, d.in_h - 1);
-            const int gx = clampi(tx_ * 32 + px + d.off_x, 0, d.in_w - 1);
+            const int gy = clampi(y0 + py, 0, d.in_h - 1);
+            const int gx = clampi(x0 + px, 0, d.in_w - 1);
             goff[jj] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 2) + q;
         }
     };
