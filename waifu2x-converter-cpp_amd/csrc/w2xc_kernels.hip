@@ -1026,15 +1026,15 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
     if (kind == W2XC_K_MFMA) {
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
-        // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0.  Measured inside the 7-layer model:
-        // 8 waves (two per SIMD) win on 128->128 only, 4 waves elsewhere (W2XC_MFMA_V2=3 forces 8 where
-        // the plane-block count divides, =1 forces 4); 32->32 stays on conv3x3_mfma (measured faster).
+        // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0 (conv3x3_mfma, the first-generation
+        // kernel, kept as a fallback).  Measured inside the 7-layer model: 8 waves (two per SIMD) win on
+        // 128->128 only, 4 waves elsewhere (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
         const int v2 = mfma_v2_enabled();
         if (v2 != 0) {
             const bool w8 = (v2 == 3) || (v2 < 0 && key == 128128);
             switch (key) {
             //                                  CIN  COUT  MB NB WM WN
-            case 32032:  if (v2 > 0) return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream); break;
+            case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
             case 32064:  return w8 ? launch_mfma2<32, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
             case 32128:  return w8 ? launch_mfma2<32, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
             case 64032:  return launch_mfma2<64, 32, 2, 1, 4, 1>(d, stream);
