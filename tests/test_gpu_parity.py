@@ -485,3 +485,30 @@ def test_cli_shell_end_to_end(gpu, models_dir, tmp_path):
     want = orc.process_image_u8(np.ascontiguousarray(rgb[:, :, ::-1]), no, so, 1, 0.75)[:, :, ::-1]
     assert got.shape == want.shape == (30, 45, 3)
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1
+
+
+def test_mfma2_race_screen(gpu, scale_layers):
+    """conv3x3_mfma2 orders its LDS-DMA transfers with hand-counted vmcnt + raw barriers.  It is deterministic by
+    construction, so a protocol error (a transfer landing late, a ring slot overwritten early) would surface as
+    run-to-run differences, most likely under memory load: repeat on the same input with and without a
+    competing HBM stream, demand bit-identical planes (tools/stress_determinism.py is the long form)."""
+    torch = pytest.importorskip("torch")
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    o = gpu.make_opts(device=0)
+    st = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    junk = torch.rand(4096, 4096, device="cuda")
+    for (h, w) in [(700, 1900), (257, 1025)]:
+        x = torch.rand(h, w, device="cuda")
+        ref = torch.empty_like(x)
+        ms.convert_device(x.data_ptr(), w * 4, w, h, ref.data_ptr(), w * 4, stream=st.cuda_stream, opts=o)
+        torch.cuda.synchronize()
+        for it in range(6):
+            y = torch.empty_like(x)
+            if it % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(10):
+                        junk = junk * 1.0001 + 0.1
+            ms.convert_device(x.data_ptr(), w * 4, w, h, y.data_ptr(), w * 4, stream=st.cuda_stream, opts=o)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), "run %d of %dx%d differs" % (it, h, w)
