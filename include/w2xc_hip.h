@@ -104,7 +104,9 @@ int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, i
 
 /* Same contract with DEVICE pointers on device opts->device, enqueued on `hip_stream`
  * (a hipStream_t; NULL = the null stream) and NOT synchronised on return.  Input and output
- * stay resident in HBM: this is what bench.py times. */
+ * stay resident in HBM: this is what bench.py times.  The enqueued kernels use the model's per-device
+ * activation workspace, so asynchronous calls on the same (model, device) must share one stream (or be
+ * serialised by the caller); different models or devices are independent. */
 int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h,
                               float *d_out, size_t out_stride_bytes, void *hip_stream,
                               const w2xc_opts *opts);

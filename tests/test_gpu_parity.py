@@ -512,3 +512,25 @@ def test_mfma2_race_screen(gpu, scale_layers):
             ms.convert_device(x.data_ptr(), w * 4, w, h, y.data_ptr(), w * 4, stream=st.cuda_stream, opts=o)
             torch.cuda.synchronize()
             assert torch.equal(y, ref), "run %d of %dx%d differs" % (it, h, w)
+
+
+def test_host_multi_band_path(gpu, scale_layers, tmp_path):
+    """the in-process multi-device path of w2xc_convert_plane / _nn2x (one host thread per band: upload band +
+    halo rows, convert, download band) -- on a 1-GPU box W2XC_HOST_BANDS=3 runs its three bands on the same
+    device.  Result must be bit-identical to the single-band run (read in a subprocess: env is read per call)."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
+        "x = np.random.default_rng(4).random((101, 77), dtype=np.float32)\n"
+        "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert_nn2x(x)[:101, :77]]))\n" % ROOT)
+    outs = []
+    for bands in ("1", "3"):
+        f = str(tmp_path / ("o%s.npy" % bands))
+        env = dict(os.environ, W2XC_HOST_BANDS=bands)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])

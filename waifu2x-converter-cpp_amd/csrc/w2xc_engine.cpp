@@ -601,6 +601,16 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     if (devs.empty()) return fail(W2XC_ERR_ARG, "device_mask 0x%x selects no available device (%d present)", o.device_mask, ndev_all);
     const int n = (int)m->layers.size();
     int nd = (int)devs.size();
+    // W2XC_HOST_BANDS=<k> (test aid): cut the plane into k host bands, round-robin over the selected devices,
+    // so the multi-device band arithmetic below can be exercised on a single-GPU box
+    if (const char *e = getenv("W2XC_HOST_BANDS")) {
+        const int k = atoi(e);
+        if (k > nd) {
+            const size_t have = devs.size();
+            for (int i = (int)have; i < k && i < 64; i++) devs.push_back(devs[i % have]);
+            nd = (int)devs.size();
+        }
+    }
     if (nd > H) nd = H;
 
     std::vector<int> rcs(nd, W2XC_OK);
@@ -624,15 +634,17 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
             HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)w * 4, (const char *)in + (size_t)sy0 * in_stride_bytes, in_stride_bytes,
                                      (size_t)w * 4, svh, hipMemcpyHostToDevice, st));
             {
+                // the context (its activation workspace) stays locked until this band's stream has drained:
+                // with one band per device that is free, and it keeps bands that share a device correct
                 std::lock_guard<std::mutex> lk(c->mu);
                 r = run_rows(m, c, d_in, w, svh << up, sy0 << up, W, ra, rb, d_out, W, st, o, up);
-            }
-            if (r == W2XC_OK) {
-                HIP_TRY(hipMemcpy2DAsync((char *)out + (size_t)ra * out_stride_bytes, out_stride_bytes, d_out, (size_t)W * 4,
-                                         (size_t)W * 4, rb - ra, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-            } else {
-                hipStreamSynchronize(st);
+                if (r == W2XC_OK) {
+                    HIP_TRY(hipMemcpy2DAsync((char *)out + (size_t)ra * out_stride_bytes, out_stride_bytes, d_out, (size_t)W * 4,
+                                             (size_t)W * 4, rb - ra, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                } else {
+                    hipStreamSynchronize(st);
+                }
             }
             hipFree(d_in);
             hipFree(d_out);
