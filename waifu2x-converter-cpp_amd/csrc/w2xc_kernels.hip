@@ -284,10 +284,24 @@ static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned v
                  : "memory", "m0");
 }
 #define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// s_waitcnt vmcnt(n) for an n that constant-folds after unrolling; the queue holds at most 63 entries
+static __device__ __forceinline__ void wait_vmcnt_n(int n)
+{
+#define W2XC_WC(k) case k: W2XC_WAIT_VMCNT(k); break;
+#define W2XC_WC8(k) W2XC_WC(k) W2XC_WC(k + 1) W2XC_WC(k + 2) W2XC_WC(k + 3) W2XC_WC(k + 4) W2XC_WC(k + 5) W2XC_WC(k + 6) W2XC_WC(k + 7)
+    switch (n) {
+        W2XC_WC8(0) W2XC_WC8(8) W2XC_WC8(16) W2XC_WC8(24) W2XC_WC8(32) W2XC_WC8(40) W2XC_WC8(48)
+        W2XC_WC(56) W2XC_WC(57) W2XC_WC(58) W2XC_WC(59) W2XC_WC(60) W2XC_WC(61) W2XC_WC(62)
+    default: break;
+    }
+#undef W2XC_WC8
+#undef W2XC_WC
+}
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int EPI = 1>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
 {
+    constexpr int NST = MB * NB * 16;                // stores per wave in an interior-tile epilogue
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
     constexpr int NSL = CIN / 32, NBT = COUT / 32;
     constexpr int NW = WM * WN;                      // 4 waves (one per SIMD) or 8 (two per SIMD)
@@ -411,6 +425,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     unsigned gs = 0;      // global stage counter (only gs & 3 matters): ring slot of the current stage
     unsigned abuf = 0;    // A buffer of the current slice
     int sl = 0;
+    bool epi_stores = false;   // an interior-tile epilogue (NST stores) directly precedes the current stage
     f32x4 a_cur[MB], b_cur[NB];
 #pragma unroll
     for (int mb = 0; mb < MB; mb++) a_cur[mb] = *a_addr(0, mb, 0, 0);
@@ -470,7 +485,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                             }
 #pragma unroll
                             for (int r = 0; r < R; r++) {
-                                if (m == 6 + (r * (M - 8)) / R) {         // reads spread over MFMAs 6 .. M-3
+                                if (m == 1 + (r * (M - 5)) / R) {         // reads spread over MFMAs 1 .. M-5: >= 4 MFMAs cover the LDS latency
                                     __builtin_amdgcn_sched_barrier(0);
                                     if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
                                     else b_nxt[r - MB] = *b_addr(bbuf_n, c8_n, r - MB);
@@ -489,14 +504,13 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
             // KA[t] + BPW issued in stage t (vmcnt retires in order; the epilogue stores of the
             // previous tile, if any, are older than stage t's transfers and are retired too).
             {
-                switch (KA[tap] + BPW) {
-                case 1: W2XC_WAIT_VMCNT(1); break;
-                case 2: W2XC_WAIT_VMCNT(2); break;
-                case 3: W2XC_WAIT_VMCNT(3); break;
-                case 4: W2XC_WAIT_VMCNT(4); break;
-                case 5: W2XC_WAIT_VMCNT(5); break;
-                default: W2XC_WAIT_VMCNT(6); break;
-                }
+                // After an interior-tile epilogue exactly NST stores sit in the queue between B(t+2) and
+                // stage t's transfers: counting them in lets the stores drain under the next two stages
+                // instead of stalling the first one (n >= 63 = queue depth: nothing to wait for).
+                const int n_dma = KA[tap] + BPW;
+                if (EPI && tap == 0 && epi_stores) wait_vmcnt_n(n_dma + NST);
+                else wait_vmcnt_n(n_dma);
+                if (tap == 0) epi_stores = false;
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -523,6 +537,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                             obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
                             acc[mb][nb][r] = 0.0f;
                         }
+                epi_stores = true;
             } else {
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++) {
