@@ -41,6 +41,12 @@ typedef struct w2xc_model w2xc_model;
                                  * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
                                  * accumulate, bias and LeakyReLU; first / last layer arithmetic stays
                                  * fp32.  Not the reference's arithmetic: tolerance in DESIGN.md 4.  */
+#define W2XC_PRECISION_BF16X2 2 /* w2xc_convert_* only: split-bf16.  Every fp32 activation / weight of layers
+                                 * 2..n-1 is carried as the sum of 2 bf16 terms (hi + lo, ~16 mantissa bits)
+                                 * and each product is 3 bf16 MFMA products accumulated in fp32.          */
+#define W2XC_PRECISION_BF16X3 3 /* as above with 3 terms (~24 mantissa bits) and 6 products: the error level
+                                 * of an fp32 FMA chain at 2.7x the fp32 MFMA rate of CDNA4.  First / last
+                                 * layer arithmetic stays fp32 MFMA in both.  Tolerances in DESIGN.md 4.   */
 
 #define W2XC_KERNEL_AUTO    0   /* MFMA implicit-GEMM where the layer shape allows                 */
 #define W2XC_KERNEL_DIRECT  1   /* reference-ordered direct conv on VALU (bit-exact vs the oracle) */

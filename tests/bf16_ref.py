@@ -24,3 +24,44 @@ def convert_bf16_emulated(layers, plane):
         if k < n - 1:
             t = _bf16(t)
     return t[0, 0].to(torch.float32).numpy()
+
+
+# ---- W2XC_PRECISION_BF16X2 / BF16X3 (w2xc_split.hip) ----------------------------------------------------
+PRODUCTS = {1: [(0, 0)], 2: [(1, 0), (0, 1), (0, 0)], 3: [(1, 1), (2, 0), (0, 2), (1, 0), (0, 1), (0, 0)]}   # (activation term, weight term)
+
+
+def _split(t, terms):
+    """fp32 tensor -> list of `terms` bf16-valued float64 tensors: a0 = bf16(a), a1 = bf16(a - a0), ... (RNE)."""
+    r = t.to(torch.float32)
+    out = []
+    for _ in range(terms):
+        h = r.to(torch.bfloat16).to(torch.float32)
+        out.append(h.to(torch.float64))
+        r = r - h          # exact in fp32
+    return out
+
+
+def convert_split_emulated(layers, plane, terms, n_in=1):
+    """Dataflow of the split-bf16 pipeline with float64 accumulation: fp32 first layer; every mid layer
+    (cin, cout in {32,64,128}, not first) sums PRODUCTS[terms] of the bf16 terms of its fp32 input and
+    weights; fp32 last layer.  `plane` is (h, w) or (n_in, h, w); returns all output planes."""
+    n = len(layers)
+    x = np.ascontiguousarray(plane, dtype=np.float32)
+    t = torch.from_numpy(x).reshape(1, n_in, x.shape[-2], x.shape[-1])
+    t = F.pad(t.to(torch.float64), (n, n, n, n), mode="replicate").to(torch.float32)
+    mid = lambda c: c in (32, 64, 128)
+    for k, (nin, nout, w, b) in enumerate(layers):
+        bias = torch.from_numpy(b.astype(np.float32)).to(torch.float64)
+        wt = torch.from_numpy(w)
+        if k > 0 and mid(nin) and mid(nout):
+            xs, ws = _split(t, terms), _split(wt, terms)
+            acc = None
+            for (ta, tb) in PRODUCTS[terms]:
+                p = F.conv2d(xs[ta], ws[tb])
+                acc = p if acc is None else acc + p
+            y = acc + bias.view(1, -1, 1, 1)
+        else:
+            y = F.conv2d(t.to(torch.float64), wt.to(torch.float64), bias)
+        y = y.to(torch.float32)                       # the accumulator is fp32
+        t = torch.where(y > 0, y, np.float32(0.1) * y)
+    return t[0].numpy()

@@ -357,6 +357,101 @@ def test_bf16_unsupported_shapes_are_rejected(gpu):
     assert e.value.code == gpu.ERR_UNSUPPORTED
 
 
+# ---- W2XC_PRECISION_BF16X2 / BF16X3: split-bf16 products on the bf16 MFMA (w2xc_split.hip) ---------------------
+def _prec(gpu, terms):
+    return {2: gpu.PRECISION_BF16X2, 3: gpu.PRECISION_BF16X3}[terms]
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("planes", [[1, 32, 32, 1], [1, 64, 128, 1], [1, 128, 64, 32, 1], [1, 32, 128, 128, 64, 1],
+                                    [1, 128, 32, 64, 1], [1, 32, 32, 64, 64, 128, 128, 1]])
+@pytest.mark.parametrize("h,w", [(45, 77), (8, 32), (70, 130)])
+def test_split_path_matches_its_emulation(gpu, terms, planes, h, w):
+    """Layers 2..n-1 carry every fp32 activation / weight as `terms` bf16 terms and sum 3 (terms = 2) or 6
+    (terms = 3) term products in the fp32 accumulator of the bf16 MFMA.  Checked against a float64-accumulate
+    emulation of exactly that dataflow: only the fp32 accumulation order differs, so the bound is the fp32
+    path's own (2e-5 of the output range); a dropped / duplicated product or a layout bug misses it by
+    orders of magnitude (the next product down is 2^-16 resp. 2^-24 of the result)."""
+    import bf16_ref
+    layers = small_layers(planes, 700 + len(planes) + terms)
+    ms = gpu._ModelSet.from_layers(layers)
+    x = rand_plane(h, w, 9 + h)
+    got = ms.convert(x, opts=gpu.make_opts(precision=_prec(gpu, terms)))
+    want = bf16_ref.convert_split_emulated(layers, x, terms)[0]
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got - want).max())
+    print("bf16x%d %s %dx%d: max err / range vs emulation %.3g" % (terms, planes, h, w, err / scale))
+    assert err <= 2e-5 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("terms,bound", [(2, 2e-4), (3, 2e-5)])
+def test_split_vs_fp32_oracle_accuracy_statement(gpu, scale_layers, terms, bound):
+    """Stated accuracy vs the CPU convertRoutine (fp32) on the 7-layer scale2.0x topology: BF16X3 is inside the
+    north-star fp32 tolerance (rtol 1e-4 / atol 1e-5, and <= 2e-5 of the output range: the level at which two
+    fp32 summation orders differ); BF16X2 is <= 2e-4 of the range.  Banding and the fused nearest-neighbour 2x
+    compose bit-identically, as on the fp32 path."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(96, 128, 3)
+    want = orc.Oracle(scale_layers).convert(x)
+    o = gpu.make_opts(precision=_prec(gpu, terms))
+    got = ms.convert(x, opts=o)
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got - want).max())
+    print("bf16x%d vs oracle32: max err / range %.3g, PSNR %.1f dB" % (terms, err / scale, psnr(got, want)))
+    assert err <= bound * scale, (err, scale)
+    if terms == 3:
+        assert_close(got, want, "bf16x3 vs oracle")
+    assert np.array_equal(got, ms.convert(x, opts=gpu.make_opts(precision=_prec(gpu, terms), band_rows=17)))
+    half = np.ascontiguousarray(x[::2, ::2])
+    up = np.repeat(np.repeat(half, 2, 0), 2, 1)
+    assert np.array_equal(ms.convert_nn2x(half, o), ms.convert(up, opts=o))
+
+
+def test_split_unsupported_shapes_are_rejected(gpu):
+    for planes in ([1, 5, 1], [32, 32, 1], [1, 32, 7, 1]):
+        ms = gpu._ModelSet.from_layers(small_layers(planes, 2))
+        x = rand_plane(8, 8, 0)
+        with pytest.raises(gpu.W2xcError) as e:
+            if planes[0] == 1:
+                ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16X3))
+            else:
+                ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16X3))
+        assert e.value.code in (gpu.ERR_UNSUPPORTED, gpu.ERR_PLANES)
+    ms2 = gpu._ModelSet.from_layers(small_layers([1, 32, 1], 2))
+    with pytest.raises(gpu.W2xcError) as e:
+        ms2.filter(0, rand_plane(8, 8, 0)[None], gpu.make_opts(precision=gpu.PRECISION_BF16X3))
+    assert e.value.code == gpu.ERR_UNSUPPORTED
+    # first -> last only: nothing to split, runs as fp32
+    x = rand_plane(20, 20, 1)
+    assert np.array_equal(ms2.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16X3)), ms2.convert(x))
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+def test_split_multi_plane_and_image_pipeline(gpu, scale_layers, terms):
+    torch = pytest.importorskip("torch")
+    import bf16_ref
+    planes = [3, 128, 128, 3]
+    layers = small_layers(planes, 31)
+    ms = gpu._ModelSet.from_layers(layers)
+    h, w = 30, 44
+    x = np.random.default_rng(8).random((3, h, w), dtype=np.float32)
+    want = bf16_ref.convert_split_emulated(layers, x, terms, n_in=3)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((3, h, w), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    ms.convert_planes_device(3, d_in.data_ptr(), h * w * 4, w * 4, w, h, d_out.data_ptr(), h * w * 4, w * 4,
+                             stream=st.cuda_stream, opts=gpu.make_opts(device=0, precision=_prec(gpu, terms)))
+    st.synchronize()
+    assert np.abs(d_out.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    # the uint8 image pipeline: the split precisions change at most the odd rounding tie
+    img = np.random.default_rng(4).integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+    mscale = gpu._ModelSet.from_layers(scale_layers)
+    a = mscale.scale2x_image_u8(img, opts=gpu.make_opts(precision=_prec(gpu, terms)))
+    b = mscale.scale2x_image_u8(img)
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= (2e-3 if terms == 3 else 2e-2), (d.max(), (d != 0).mean())
+
+
 @pytest.mark.parametrize("planes", [[3, 128, 128, 3], [3, 32, 64, 2], [2, 5, 4], [1, 32, 32]])
 def test_multi_plane_wrapper(gpu, planes):
     """w2xc_convert_planes_device (configs[4] boundary): pad n / layers / crop on several planes equals the

@@ -11,11 +11,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=128); ap.add_argument("--cout", type=int, default=128)
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16x2, 3 bf16x3 (split modes time a T->T mid layer: model 1->cin->cout->cout->1)")
 a = ap.parse_args()
 w2xc = graft.load_package()
-ms = w2xc._ModelSet.from_layers(gen_model.synth_layers([1, a.cin, a.cout, 1], 7))
+topo = [1, a.cin, a.cout, 1] if a.precision < 2 else [1, a.cin, a.cout, a.cout, 1]
+ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(topo, 7))
 x = torch.rand(a.h, a.w, device="cuda"); y = torch.empty_like(x)
-o = w2xc.make_opts(device=0, profile=1)
+o = w2xc.make_opts(device=0, profile=1, precision=a.precision)
 st = torch.cuda.current_stream()
 for i in range(a.steps + 1):
     if i == 1: torch.cuda.synchronize(); ms.profile_reset(0)
@@ -24,4 +26,4 @@ torch.cuda.synchronize()
 t, n = ms.profile_read(0)
 t2 = t[1] / n[1]
 flops = 18.0 * a.cin * a.cout * (a.h + 2) * (a.w + 2)
-print("variant=%s %d->%d %dx%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (os.environ.get("W2XC_MFMA_VARIANT", "0"), a.cin, a.cout, a.h, a.w, t2, flops / t2 / 1e9, flops / t2 / 1e9 / 1.573))
+print("precision=%d %d->%d %dx%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)  all layers: %s" % (a.precision, a.cin, a.cout, a.h, a.w, t2, flops / t2 / 1e9, flops / t2 / 1e9 / 1.573, " ".join("%.3f" % (t[i] / n[i]) for i in range(len(t)))))

@@ -1,0 +1,67 @@
+// w2xc_device.h -- device-side helpers shared by the gfx950 kernel files (w2xc_kernels.hip, w2xc_split.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cv::max / cv::min / cv::scaleAdd(neg, 0.1, pos), modelHandler.cpp:148-152
+static __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : 0.1f * v; }
+
+// bf16 storage (round-to-nearest-even; finite values only on this path)
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ bf16_t f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static __device__ __forceinline__ void store_act(float *p, float v) { *p = v; }
+static __device__ __forceinline__ void store_act(bf16_t *p, float v) { *p = f2bf(v); }
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each XCD one contiguous
+// range of tiles so neighbouring tiles (which share halo rows/columns) share an L2.  Bijective
+// for any grid size (cdna_hip_programming.md T1).
+static __device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- LDS-DMA (global_load_lds_dwordx4) and counted waits ----------------------------------------
+// m0 carries the wave-uniform LDS byte address of the transfer; it is compiler-reserved and this
+// kernel uses it for nothing else, so it is simply overwritten (clobber listed: hipcc only warns).
+static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(gptr), "s"(lds_byte_addr)
+                 : "memory", "m0");
+}
+// scalar base + 32-bit per-lane byte offset + immediate: no 64-bit VALU address per transfer
+template <int IMM>
+static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
+                 : "memory", "m0");
+}
+#define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// s_waitcnt vmcnt(n) for an n that constant-folds after unrolling; the queue holds at most 63 entries
+static __device__ __forceinline__ void wait_vmcnt_n(int n)
+{
+#define W2XC_WC(k) case k: W2XC_WAIT_VMCNT(k); break;
+#define W2XC_WC8(k) W2XC_WC(k) W2XC_WC(k + 1) W2XC_WC(k + 2) W2XC_WC(k + 3) W2XC_WC(k + 4) W2XC_WC(k + 5) W2XC_WC(k + 6) W2XC_WC(k + 7)
+    switch (n) {
+        W2XC_WC8(0) W2XC_WC8(8) W2XC_WC8(16) W2XC_WC8(24) W2XC_WC8(32) W2XC_WC8(40) W2XC_WC8(48)
+        W2XC_WC(56) W2XC_WC(57) W2XC_WC(58) W2XC_WC(59) W2XC_WC(60) W2XC_WC(61) W2XC_WC(62)
+    default: break;
+    }
+#undef W2XC_WC8
+#undef W2XC_WC
+}

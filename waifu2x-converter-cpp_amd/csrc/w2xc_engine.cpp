@@ -67,6 +67,7 @@ struct DevLayer {
     float *w_fast = nullptr;
     float *w_direct = nullptr;
     float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
+    float *w_split[4] = {nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images per term count, packed on first use
     float *bias = nullptr;
 };
 
@@ -96,6 +97,8 @@ struct DevCtx {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_bf16) hipFree(l.w_bf16);
+            for (float *p : l.w_split)
+                if (p) hipFree(p);
             if (l.bias) hipFree(l.bias);
         }
         for (int i = 0; i < 2; i++)
@@ -148,20 +151,51 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
     return r;
 }
 
+// bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline).
+// W2XC_PRECISION_BF16 runs through it as the one-term case when W2XC_BF16_PIPE=split (tuning aid).
+int split_terms(const w2xc_opts &o)
+{
+    if (o.precision == W2XC_PRECISION_BF16X2) return 2;
+    if (o.precision == W2XC_PRECISION_BF16X3) return 3;
+    if (o.precision == W2XC_PRECISION_BF16) {
+        static int v = -1;
+        if (v < 0) { const char *e = getenv("W2XC_BF16_PIPE"); v = (e && !strcmp(e, "split")) ? 1 : 0; }
+        return v;
+    }
+    return 0;
+}
+
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     if (o.kernel == W2XC_KERNEL_DIRECT) return W2XC_K_DIRECT;
     const W2xcKernelKind k = w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout);
+    const int n = (int)m->layers.size();
+    if (split_terms(o) > 0) {
+        // term planes live only BETWEEN a first/mid layer and a mid layer; everything that touches the
+        // caller's planes or the last layer is fp32.  Shapes without an MFMA kernel are unsupported.
+        if (k == W2XC_K_MFMA) return l > 0 ? W2XC_K_MID_SPLIT : W2XC_K_DIRECT;
+        if (k == W2XC_K_FIRST && l == 0)
+            return (n > 1 && w2xc_pick_kernel(m->layers[1].nin, m->layers[1].nout) == W2XC_K_MFMA) ? W2XC_K_FIRST_SPLIT : W2XC_K_FIRST;
+        if (k == W2XC_K_LAST && l == n - 1 && l > 0) return W2XC_K_LAST;
+        return W2XC_K_DIRECT;   // run_rows rejects this
+    }
     if (o.precision == W2XC_PRECISION_BF16) {
         // bf16 activations live only BETWEEN layers: the first layer reads the caller's fp32 plane, the
         // last one writes it; anything else (or a shape without an MFMA kernel) is unsupported
-        const int n = (int)m->layers.size();
         if (l == 0 && k == W2XC_K_FIRST && m->layers[l].nin == 1) return W2XC_K_FIRST_BF16OUT;
         if (l == n - 1 && k == W2XC_K_LAST && m->layers[l].nout == 1) return W2XC_K_LAST_BF16IN;
         if (l > 0 && l < n - 1 && k == W2XC_K_MFMA) return W2XC_K_MFMA_BF16;
         return W2XC_K_DIRECT;   // run_rows rejects this for bf16
     }
     return k;
+}
+
+// terms of layer l's OUTPUT in the split pipeline: T when layer l+1 is a split mid layer, else 0 (fp32)
+int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
+{
+    const int T = split_terms(o), n = (int)m->layers.size();
+    if (T == 0 || l + 1 >= n) return 0;
+    return layer_kind(m, l + 1, o) == W2XC_K_MID_SPLIT ? T : 0;
 }
 
 int upload(const std::vector<float> &h, float **d)
@@ -244,11 +278,24 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         int rc = upload(pk, &dl.w_bf16);
         if (rc) return rc;
     }
-    d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
+    if (kind == W2XC_K_MID_SPLIT) {
+        if (d.terms < 1 || d.terms > 3) return fail(W2XC_ERR_ARG, "bad term count %d", d.terms);
+        if (!dl.w_split[d.terms]) {
+            std::vector<float> pk((w2xc_split_packed_bytes(d.cin, d.cout, d.terms) + 3) / 4);
+            w2xc_split_pack(d.cin, d.cout, d.terms, m->layers[l].w.data(), pk.data());
+            int rc = upload(pk, &dl.w_split[d.terms]);
+            if (rc) return rc;
+        }
+        d.wpk = dl.w_split[d.terms];
+    } else {
+        d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
+    }
     d.bias = dl.bias;
     ProfEvent ev;
     if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
-    hipError_t e = w2xc_launch_conv(kind, d, st);
+    hipError_t e = kind == W2XC_K_MID_SPLIT     ? w2xc_launch_split_mid(d, st)
+                   : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
+                                                : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
         HIP_TRY(hipEventRecord(ev.b, st));
@@ -276,8 +323,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     for (int l = 1; l < n; l++)
         if (m->layers[l].nin != m->layers[l - 1].nout)
             return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
-    const bool bf16 = (o.precision == W2XC_PRECISION_BF16);
-    if (o.precision != W2XC_PRECISION_FP32 && !bf16) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
+    const int T = split_terms(o);
+    const bool bf16 = (o.precision == W2XC_PRECISION_BF16) && T == 0;
+    if (o.precision != W2XC_PRECISION_FP32 && !bf16 && T == 0) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
     if (bf16) {
         if (n < 2 || m->layers[n - 1].nout != 1) return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16 needs >= 2 layers ending in one plane");
         for (int l = 0; l < n; l++)
@@ -285,7 +333,17 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16: layer %d (%d->%d) has no bf16 kernel (1->{32,64,128}, {32,64,128}->{32,64,128}, ->1 only)",
                             l + 1, m->layers[l].nin, m->layers[l].nout);
     }
-    const size_t esz_div = bf16 ? 2 : 1;   // workspace elements per float slot
+    if (T > 0)
+        for (int l = 0; l < n; l++)
+            if (layer_kind(m, l, o) == W2XC_K_DIRECT)
+                return fail(W2XC_ERR_UNSUPPORTED, "split-bf16 precision: layer %d (%d->%d) has no kernel ({1,3}->{32,64,128} first, {32,64,128}->{32,64,128}, ->{1,3} last only)",
+                            l + 1, m->layers[l].nin, m->layers[l].nout);
+    // bytes per activation element of layer k's output (k = 1..n) in the workspace
+    auto out_bpe = [&](int k) -> size_t {
+        if (bf16) return 2;
+        const int ot = out_terms_of(m, k - 1, o);
+        return ot ? 2 * (size_t)ot : 4;
+    };
 
     // the last layer stores straight into the caller's planar plane(s) when its kernel can address planar
     // output (conv3x3_last / conv3x3_direct); otherwise it goes through the NHWC workspace + a repack
@@ -293,13 +351,13 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     const bool last_direct = (m->layers[n - 1].nout == 1 || all_out) &&
                              (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_BF16IN || last_kind == W2XC_K_DIRECT ||
                               (m->layers[n - 1].nout == 1 && last_kind != W2XC_K_MFMA && last_kind != W2XC_K_FIRST));
-    // floats per band row for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
+    // BYTES per band for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
     auto ws_need = [&](int rows, size_t need[2]) {
         need[0] = need[1] = 0;
         for (int k = 1; k <= n; k++) {
             if (k == n && last_direct) break;   // written straight to d_out
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
-            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * m->layers[k - 1].nout);
+            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * m->layers[k - 1].nout * out_bpe(k));
         }
     };
     int band = o.band_rows;
@@ -308,14 +366,14 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         const size_t budget = (size_t)(o.workspace_mb > 0 ? o.workspace_mb : 16384) << 20;
         size_t need[2];
         ws_need(total, need);
-        if ((need[0] + need[1]) * sizeof(float) / esz_div <= budget) band = total;
+        if (need[0] + need[1] <= budget) band = total;
         else {
             // bytes grow linearly in rows: solve on two probes
             size_t n1[2], n2[2];
             ws_need(1, n1);
             ws_need(2, n2);
-            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1])) * sizeof(float) / esz_div;
-            const double base = (double)(n1[0] + n1[1]) * sizeof(float) / esz_div - per_row;
+            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1]));
+            const double base = (double)(n1[0] + n1[1]) - per_row;
             band = (int)std::floor(((double)budget - base) / per_row);
             if (band < 1) band = 1;
             const int nb = (total + band - 1) / band;
@@ -327,13 +385,13 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         size_t need[2];
         ws_need(band, need);
         for (int i = 0; i < 2; i++)
-            if (need[i]) { int rc = ensure_ws(c, i, (need[i] + esz_div - 1) / esz_div); if (rc) return rc; }
+            if (need[i]) { int rc = ensure_ws(c, i, (need[i] + 3) / 4); if (rc) return rc; }
     }
 
     for (int y0 = ra; y0 < rb; y0 += band) {
         const int y1 = std::min(rb, y0 + band);
         const float *src = d_in;
-        long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs;
+        long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs, src_ts = 0, src_gs = 0;
         int src_h = vh, src_w = w;
         for (int k = 1; k <= n; k++) {
             if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
@@ -347,6 +405,17 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.off_y = k == 1 ? (y0 - n - vy0) : 0;
             d.off_x = k == 1 ? -n : 0;
             d.in_shift = k == 1 ? up : 0;
+            const W2xcKernelKind kind = layer_kind(m, k - 1, o);
+            int split_grp = 0;
+            if (T > 0) {
+                d.terms = (kind == W2XC_K_MID_SPLIT) ? T : 0;
+                d.in_ts = src_ts;
+                d.out_terms = out_terms_of(m, k - 1, o);
+                d.out_ts = (long long)d.out_h * d.out_w * hl.nout;
+                d.in_gs = src_gs;
+                split_grp = d.out_terms == 3 ? 16 : 32;                 // channel-group size of the blocked term planes
+                d.out_gs = (long long)d.out_h * d.out_w * split_grp;
+            }
             const bool direct_out = (k == n && last_direct);
             if (direct_out) {
                 d.out = d_out + (size_t)(y0 - ra) * out_stride_f;
@@ -354,8 +423,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             } else {
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
+                if (T > 0 && d.out_terms > 0) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
             }
-            int rc = launch_layer(c, m, k - 1, layer_kind(m, k - 1, o), d, st, o.profile != 0);
+            int rc = launch_layer(c, m, k - 1, kind, d, st, o.profile != 0);
             if (rc) return rc;
             if (k == n && !direct_out) {
                 // outputPlanes[0] of a multi-plane last layer (convertRoutine.cpp:78)
@@ -363,7 +433,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                                                   (long long)out_stride_f, 1, out_cs, d.out_h, d.out_w, all_out ? hl.nout : 1, st);
                 if (e != hipSuccess) return fail(W2XC_ERR_HIP, "repack launch failed: %s", hipGetErrorString(e));
             }
-            src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs;
+            src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs;
             src_h = d.out_h; src_w = d.out_w;
         }
     }
@@ -695,7 +765,8 @@ int w2xc_convert_planes_device(w2xc_model *m, int n_in_planes, const float *d_in
         (n_in_planes > 1 && in_plane_stride_bytes < in_stride_bytes * (size_t)h) || out_plane_stride_bytes < out_stride_bytes * (size_t)h)
         return fail(W2XC_ERR_ARG, "bad plane count / plane strides");
     const w2xc_opts o = resolve_opts(opts);
-    if (o.precision != W2XC_PRECISION_FP32) return fail(W2XC_ERR_UNSUPPORTED, "w2xc_convert_planes_* is fp32 only");
+    if (o.precision != W2XC_PRECISION_FP32 && split_terms(o) == 0)
+        return fail(W2XC_ERR_UNSUPPORTED, "w2xc_convert_planes_* supports W2XC_PRECISION_FP32 / BF16X2 / BF16X3");
     int dev = o.device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);

@@ -25,6 +25,11 @@ struct W2xcConvDesc {
     // in UPSCALED coordinates, memory is addressed at (y >> in_shift, x >> in_shift).  0 or 1; only the
     // first-layer kernels (conv3x3_first, conv3x3_direct) honour it.
     int in_shift;
+    // split-bf16 kernels (w2xc_split.hip): an activation tensor is `terms` bf16 term planes, each channel-group
+    // blocked: element (t, c, y, x) at t*ts + (c / G)*gs + y*rs + x*G + c % G  (ELEMENTS; G = 16 for 3 terms, else 32).
+    // out_terms = 0 stores plain fp32 NHWC.
+    int terms, out_terms;
+    long long in_ts, out_ts, in_gs, out_gs;
 };
 
 enum W2xcKernelKind {
@@ -36,6 +41,9 @@ enum W2xcKernelKind {
     W2XC_K_MFMA_BF16 = 4,      // cin, cout in {32,64,128}: bf16 in/out, bf16 weights, v_mfma_f32_32x32x16_bf16
     W2XC_K_FIRST_BF16OUT = 5,  // W2XC_K_FIRST (fp32 planar in, fp32 weights) storing bf16 NHWC
     W2XC_K_LAST_BF16IN = 6,    // W2XC_K_LAST reading bf16 NHWC (widened to fp32 exactly), fp32 planar out
+    // W2XC_PRECISION_BF16X2 / BF16X3 (and BF16 through the same pipeline): fp32 values carried as d.terms bf16 terms
+    W2XC_K_MID_SPLIT = 7,      // cin, cout in {32,64,128}: term planes in, term planes (or fp32 when out_terms = 0) out
+    W2XC_K_FIRST_SPLIT = 8,    // W2XC_K_FIRST storing d.out_terms term planes
 };
 
 // Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
@@ -49,6 +57,14 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 
 // Enqueue one layer on `stream`.  Returns hipSuccess or the launch error.
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream);
+
+// split-bf16 kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` bf16 terms of every weight in
+// fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.
+int w2xc_split_kg(int terms, int cin);
+size_t w2xc_split_packed_bytes(int cin, int cout, int terms);
+void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst);
+hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream);
 
 // strided element copy (planar <-> NHWC repack at the Model::filter boundary)
 hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, long long s_cs,

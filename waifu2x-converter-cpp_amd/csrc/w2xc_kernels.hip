@@ -24,41 +24,13 @@
 //
 // fp32 MFMA on gfx950 is an exact k-ordered fmaf chain at the f32 vector rate (157.3 TF peak).
 #include "w2xc_kernels.h"
+#include "w2xc_device.h"
 
 #include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// cv::max / cv::min / cv::scaleAdd(neg, 0.1, pos), modelHandler.cpp:148-152
-static __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : 0.1f * v; }
-
-// bf16 storage (round-to-nearest-even; finite values only on this path)
-typedef unsigned short bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ bf16_t f2bf(float f)
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-static __device__ __forceinline__ void store_act(float *p, float v) { *p = v; }
-static __device__ __forceinline__ void store_act(bf16_t *p, float v) { *p = f2bf(v); }
-
-// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each XCD one contiguous
-// range of tiles so neighbouring tiles (which share halo rows/columns) share an L2.  Bijective
-// for any grid size (cdna_hip_programming.md T1).
-static __device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 // ------------------------------------------------------------------------------------------------
 // conv3x3_direct: reference-ordered VALU kernel (bit-exact vs the oracle).
@@ -265,38 +237,6 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
 //   raw s_barrier.  B(t+1) was already complete at the previous barrier, so the first fragments
 //   of stage t+1 are read BEFORE the barrier and the MFMA stream runs across it.
 // ------------------------------------------------------------------------------------------------
-// m0 carries the wave-uniform LDS byte address of the transfer; it is compiler-reserved and this
-// kernel uses it for nothing else, so it is simply overwritten (clobber listed: hipcc only warns).
-static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_byte_addr)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :
-                 : "v"(gptr), "s"(lds_byte_addr)
-                 : "memory", "m0");
-}
-// scalar base + 32-bit per-lane byte offset + immediate: no 64-bit VALU address per transfer
-template <int IMM>
-static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_byte_addr)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
-                 : "memory", "m0");
-}
-#define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-// s_waitcnt vmcnt(n) for an n that constant-folds after unrolling; the queue holds at most 63 entries
-static __device__ __forceinline__ void wait_vmcnt_n(int n)
-{
-#define W2XC_WC(k) case k: W2XC_WAIT_VMCNT(k); break;
-#define W2XC_WC8(k) W2XC_WC(k) W2XC_WC(k + 1) W2XC_WC(k + 2) W2XC_WC(k + 3) W2XC_WC(k + 4) W2XC_WC(k + 5) W2XC_WC(k + 6) W2XC_WC(k + 7)
-    switch (n) {
-        W2XC_WC8(0) W2XC_WC8(8) W2XC_WC8(16) W2XC_WC8(24) W2XC_WC8(32) W2XC_WC8(40) W2XC_WC8(48)
-        W2XC_WC(56) W2XC_WC(57) W2XC_WC(58) W2XC_WC(59) W2XC_WC(60) W2XC_WC(61) W2XC_WC(62)
-    default: break;
-    }
-#undef W2XC_WC8
-#undef W2XC_WC
-}
 
 template <int CIN, int COUT, int MB, int NB, int WM, int WN, int EPI = 1>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
@@ -889,6 +829,8 @@ const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout)
     case W2XC_K_MFMA_BF16: return "conv3x3_mfma_bf16";
     case W2XC_K_FIRST_BF16OUT: return "conv3x3_first<bf16 out>";
     case W2XC_K_LAST_BF16IN: return "conv3x3_last<bf16 in>";
+    case W2XC_K_MID_SPLIT: return "conv3x3_split";
+    case W2XC_K_FIRST_SPLIT: return "conv3x3_first_split";
     default: return "conv3x3_direct";
     }
 }
@@ -899,7 +841,7 @@ size_t w2xc_packed_weight_floats(W2xcKernelKind kind, int cin, int cout)
 {
     switch (kind) {
     case W2XC_K_MFMA: return (size_t)9 * cin * cout;
-    case W2XC_K_FIRST: case W2XC_K_FIRST_BF16OUT: return (size_t)(cout / 32) * ((9 * cin + 1) / 2) * 64;
+    case W2XC_K_FIRST: case W2XC_K_FIRST_BF16OUT: case W2XC_K_FIRST_SPLIT: return (size_t)(cout / 32) * ((9 * cin + 1) / 2) * 64;
     case W2XC_K_LAST: case W2XC_K_LAST_BF16IN: return (size_t)(cin / 16) * 4 * ((9 * cout + 15) / 16) * 64;
     case W2XC_K_MFMA_BF16: return ((size_t)9 * cin * cout + 1) / 2;   // bf16 pairs per float slot
     default: return (size_t)cin * 9 * direct_cout_pad(cout);
@@ -910,7 +852,7 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 {
     auto W = [&](int o, int i, int tap) { return w[((size_t)o * cin + i) * 9 + tap]; };
     memset(dst, 0, w2xc_packed_weight_floats(kind, cin, cout) * sizeof(float));
-    if (kind == W2XC_K_FIRST_BF16OUT) kind = W2XC_K_FIRST;
+    if (kind == W2XC_K_FIRST_BF16OUT || kind == W2XC_K_FIRST_SPLIT) kind = W2XC_K_FIRST;
     if (kind == W2XC_K_LAST_BF16IN) kind = W2XC_K_LAST;
     if (kind == W2XC_K_MFMA_BF16) {
         auto bf = [](float f) -> unsigned short {

@@ -1,0 +1,645 @@
+// w2xc_split.hip -- "split-bf16" kernels for gfx950: the 3x3xCinxCout contraction of Model::filterWorker
+// (/root/reference/src/modelHandler.cpp:117-159) on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense, 16x the fp32
+// MFMA rate of CDNA4) with every fp32 operand carried as a sum of T bf16 terms:
+//
+//     a = a0 + a1 (+ a2),  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (round to nearest even)
+//     a*b ~= sum of the NP largest term products, accumulated in fp32 inside the matrix core
+//
+//     T = 1  (W2XC_PRECISION_BF16)     1 product   8-bit operands
+//     T = 2  (W2XC_PRECISION_BF16X2)   3 products  a0b0 + a0b1 + a1b0:            ~16-bit operands, |err| ~ 2^-17 |ab|
+//     T = 3  (W2XC_PRECISION_BF16X3)   6 products  + a1b1 + a0b2 + a2b0:          ~24-bit operands, |err| ~ 2^-24 |ab|,
+//                                                                                  i.e. the error level of an fp32 FMA chain
+//
+// Activations between the layers are T planes of NHWC bf16 ("term planes", `ts` elements apart); the producer's
+// epilogue does the split once per element, so the consumer streams ready-made bf16 fragments with LDS-DMA exactly
+// like conv3x3_mfma2 streams fp32 ones.  The mid layer that feeds the last layer writes plain fp32 NHWC, so
+// conv3x3_last is used unchanged.
+//
+//   conv3x3_split        cin, cout in {32,64,128}: persistent workgroups (one per CU), tile = 8 rows x 32 pixels x COUT.
+//                        Stage = (slice of 16*KG channels, tap); LDS = A[2] (halo tile of one slice, all T terms,
+//                        32*KG bytes per pixel per term, 16-byte chunks XOR-swizzled so ds_read_b128 of 32 consecutive
+//                        pixels is conflict-free) + a ring of RING B stages (T*KG*COUT/32 KiB each, fragment order).
+//                        Operands are swapped (weights = MFMA A operand): the accumulator tile is [channel][pixel],
+//                        lane = pixel, 4 consecutive channels per register quad -> 8/16-byte stores, no LDS transpose.
+//   conv3x3_first_split  cin <= 3 (layer 1) on the fp32 MFMA exactly like conv3x3_first, storing term planes.
+#include "w2xc_kernels.h"
+#include "w2xc_device.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <type_traits>
+
+#ifndef W2XC_SPLIT_LATE
+#define W2XC_SPLIT_LATE 4   // MFMAs kept after the last fragment read of a step
+#endif
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// v_cvt_pk_bf16_f32 (round to nearest even): a -> bits 0..15, b -> bits 16..31
+static __device__ __forceinline__ unsigned pk_bf16(float a, float b)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// Store 4 consecutive channels of one pixel as OT term planes (OT >= 1) or as fp32 (OT == 0).
+template <int OT>
+static __device__ __forceinline__ void store_terms(float *out, long long elem_off, long long out_ts, float v0, float v1, float v2, float v3)
+{
+    if (OT == 0) {
+        *reinterpret_cast<f32x4 *>(out + elem_off) = (f32x4){v0, v1, v2, v3};
+    } else {
+        bf16_t *o16 = reinterpret_cast<bf16_t *>(out) + elem_off;
+#pragma unroll
+        for (int t = 0; t < OT; t++) {
+            const unsigned p01 = pk_bf16(v0, v1), p23 = pk_bf16(v2, v3);
+            *reinterpret_cast<u32x2 *>(o16 + (long long)t * out_ts) = (u32x2){p01, p23};
+            if (t + 1 < OT) {   // exact residuals: |v - bf16(v)| fits fp32
+                v0 -= __uint_as_float(p01 << 16);
+                v1 -= __uint_as_float(p01 & 0xFFFF0000u);
+                v2 -= __uint_as_float(p23 << 16);
+                v3 -= __uint_as_float(p23 & 0xFFFF0000u);
+            }
+        }
+    }
+}
+
+// term products in issue order (smallest first): activation term PA[i] x weight term PB[i]
+template <int T> struct Prod;
+template <> struct Prod<1> {
+    static constexpr int N = 1;
+    static __device__ constexpr int a(int) { return 0; }
+    static __device__ constexpr int b(int) { return 0; }
+};
+template <> struct Prod<2> {
+    static constexpr int N = 3;
+    static __device__ constexpr int a(int i) { return i == 0 ? 1 : 0; }
+    static __device__ constexpr int b(int i) { return i == 1 ? 1 : 0; }
+};
+template <> struct Prod<3> {
+    static constexpr int N = 6;
+    //                                          i:   0  1  2  3  4  5
+    static __device__ constexpr int a(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 3 ? 1 : 0; }   // 1  2  0  1  0  0
+    static __device__ constexpr int b(int i) { return i == 0 ? 1 : i == 2 ? 2 : i == 4 ? 1 : 0; }   // 1  0  2  0  1  0
+};
+
+// Fragment read order of a step = order of first use by the products above, so the fragments read last
+// are needed last: group gi of 2T is (weights? , term).  read_decode(r) -> isW*100 + term*10 + index.
+template <int T> static __device__ constexpr int grp_w(int gi) { return gi & 1; }
+template <int T> static __device__ constexpr int grp_term(int gi)
+{
+    return T == 3 ? (gi == 0 ? 1 : gi == 1 ? 1 : gi == 2 ? 2 : gi == 3 ? 0 : gi == 4 ? 0 : 2)
+         : T == 2 ? (gi == 0 ? 1 : gi == 1 ? 0 : gi == 2 ? 0 : 1)
+                  : 0;
+}
+template <int T, int MB, int NB> static __device__ constexpr int read_decode(int r)
+{
+    for (int gi = 0; gi < 2 * T; gi++) {
+        const int n = grp_w<T>(gi) ? NB : MB;
+        if (r < n) return grp_w<T>(gi) * 100 + grp_term<T>(gi) * 10 + r;
+        r -= n;
+    }
+    return -1;
+}
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [B, E)
+template <int B, int E, class F>
+static __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// A-piece schedule: APW pieces spread (ceil first) over taps 0..LASTA
+template <int APW, int LASTA> static __device__ constexpr int ka(int t) { return t <= LASTA ? (APW + LASTA - t) / (LASTA + 1) : 0; }
+template <int APW, int LASTA> static __device__ constexpr int ka_before(int tap)
+{
+    int s = 0;
+    for (int t = 0; t < tap; t++) s += ka<APW, LASTA>(t);
+    return s;
+}
+template <int APW, int LASTA> static __device__ constexpr int ka_window(int tap, int look)   // taps tap-look+1 .. tap (mod 9)
+{
+    int s = 0;
+    for (int k = 0; k < look; k++) s += ka<APW, LASTA>((tap - k + 9) % 9);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING>
+__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcConvDesc d, int tiles_x, int ntiles)
+{
+    constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW, NPIXP = 352;
+    constexpr int NCH = 2 * KG;                       // 16-byte chunks per pixel per term in one slice
+    constexpr int PXB = 32 * KG;                      // bytes per pixel per term
+    constexpr int SWS = NCH == 2 ? 3 : NCH == 4 ? 2 : 1;   // swizzle: chunk q of pixel p sits at q ^ ((p >> SWS) & (NCH-1))
+    constexpr int SLC = 16 * KG;                      // channels per slice = channel-group size of the blocked layout
+    constexpr int NSL = CIN / SLC, NBT = COUT / 32;
+    constexpr int NW = WM * WN;
+    constexpr unsigned A_TERM = NPIXP * PXB;          // bytes of one term of the halo tile (352 = 340 padded to 1 KiB pieces)
+    constexpr int A_SLOTS = T * NPIXP * NCH;          // 16-byte slots
+    constexpr int A_PIECES = A_SLOTS / 64;            // 1 KiB pieces = T * 11 * KG
+    constexpr int APW = (A_PIECES + NW - 1) / NW;     // pieces per wave per slice
+    constexpr unsigned A_BYTES = NW * APW * 1024;
+    constexpr int B_PIECES = T * KG * NBT;            // 1 KiB pieces per stage
+    constexpr int BPW = (B_PIECES + NW - 1) / NW;
+    constexpr unsigned B_BYTES = B_PIECES * 1024;
+    constexpr unsigned B_BASE = 2 * A_BYTES;
+    constexpr int NP = Prod<T>::N;
+    constexpr int LEAD = RING - 1;                    // B(t + LEAD) is issued during stage t
+    constexpr int LOOK = RING - 3;                    // stages whose transfers are younger than B(t+2) at the end of stage t
+    constexpr int LASTA = 10 - RING < 5 ? 10 - RING : 5;   // A pieces of the next slice are issued on taps 0..LASTA: landed by the end of tap 7,
+                                                           // because tap 8's last step already reads the next slice's first fragments
+    constexpr int NST = MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
+    static_assert((NW == 4 || NW == 8) && MB * WM == ROWS && NB * WN == NBT, "tile shape");
+    static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
+    static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 2, "pipeline shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nb0 = wn * NB;
+    const int li = lane & 31, kk = lane >> 5;
+
+    // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the tile list
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
+    int tile = chunk_begin + (blockIdx.x >> 3);
+    if (tile >= chunk_end) return;
+
+    // bias of the 16 channels this lane holds per plane block: channel = (r&3) + 8*(r>>2) + 4*kk
+    float bv[NB][16];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) bv[nb][r] = d.bias[(nb0 + nb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk];
+
+    // ---- per-lane DMA source offsets of the A halo tile, in 16-byte units (8 bf16) ----
+    const u32x4 *in4 = reinterpret_cast<const u32x4 *>(d.in);
+    const unsigned ts16 = (unsigned)(d.in_ts >> 3), gs16 = (unsigned)(d.in_gs >> 3);   // term / channel-group strides
+    unsigned goff[APW], lofs[APW];
+    auto slot_of = [&](int jj, int &t, int &p, int &q) {
+        int s = (jj * NW + wave) * 64 + lane;
+        s = s < A_SLOTS ? s : A_SLOTS - 1;                   // pieces past the data re-read its last slot
+        t = s / (NPIXP * NCH);
+        const int rem = s - t * (NPIXP * NCH);
+        p = rem / NCH;
+        const int qq = rem - p * NCH;
+        p = p < NPIX ? p : NPIX - 1;                         // pad pixels re-read the last pixel
+        q = qq ^ ((p >> SWS) & (NCH - 1));                   // chunk stored at this position
+    };
+#pragma unroll
+    for (int jj = 0; jj < APW; jj++) {
+        int t, p, q;
+        slot_of(jj, t, p, q);
+        const int py = p / HW, px = p - py * HW;
+        lofs[jj] = (unsigned)t * ts16 + (unsigned)(((long long)py * d.in_rs + (long long)px * SLC) >> 3) + q;
+    }
+    auto tile_offsets = [&](int tl) {
+        const int ty_ = tl / tiles_x, tx_ = tl - ty_ * tiles_x;
+        const int y0 = ty_ * ROWS + d.off_y, x0 = tx_ * 32 + d.off_x;
+        if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
+            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * SLC) >> 3);
+#pragma unroll
+            for (int jj = 0; jj < APW; jj++) goff[jj] = lofs[jj] + base;
+            return;
+        }
+#pragma unroll
+        for (int jj = 0; jj < APW; jj++) {
+            int t, p, q;
+            slot_of(jj, t, p, q);
+            const int py = p / HW, px = p - py * HW;
+            const int gy = clampi(y0 + py, 0, d.in_h - 1);
+            const int gx = clampi(x0 + px, 0, d.in_w - 1);
+            goff[jj] = (unsigned)t * ts16 + (unsigned)(((long long)gy * d.in_rs + (long long)gx * SLC) >> 3) + q;
+        }
+    };
+    auto dma_a = [&](unsigned add, unsigned abuf, int jj) {
+        lds_dma16(in4 + goff[jj] + add, lds0 + abuf * A_BYTES + (unsigned)(jj * NW + wave) * 1024u);
+    };
+    // B piece jb of this wave for stage (sl_, tap_) -> ring slot buf (a short last wave repeats the last piece)
+    const unsigned b_voff = (unsigned)lane * 16u;
+    auto dma_b = [&](int sl_, int tap_, unsigned buf, int jb) {
+        int pb = wave * BPW + jb;
+        pb = pb < B_PIECES ? pb : B_PIECES - 1;
+        // (wave-uniform by construction; readfirstlane keeps the base and the LDS address in SGPRs)
+        const unsigned goff_b = (unsigned)__builtin_amdgcn_readfirstlane(((tap_ * NSL + sl_) * B_PIECES + pb) * 1024);
+        const char *sbase = reinterpret_cast<const char *>(d.wpk) + goff_b;
+        lds_dma16_s<0>(sbase, b_voff, (unsigned)__builtin_amdgcn_readfirstlane(lds0 + B_BASE + buf * B_BYTES + (unsigned)pb * 1024u));
+    };
+
+    // ---- fragment addressing ----
+    // X (pixels): lane (li, kk) reads chunk 2g + kk of pixel p = (wm*MB + row)*34 + li + tx, term t:
+    //    byte  t*A_TERM + p*PXB + (((2g + kk) ^ sw(p)) << 4)  =  t*A_TERM + (a0[row][tx] ^ (g << 5))
+    unsigned a0[MB + 2][3];
+#pragma unroll
+    for (int row = 0; row < MB + 2; row++)
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++) {
+            const int p = (wm * MB + row) * HW + li + tx;
+            a0[row][tx] = (unsigned)(p * PXB + ((((p >> SWS) & (NCH - 1)) ^ kk) << 4));
+        }
+    auto x_addr = [&](unsigned abuf, int t, int mb, int tap, int g) -> const u32x4 * {
+        return reinterpret_cast<const u32x4 *>(ldsb + ((a0[mb + tap / 3][tap % 3] ^ (unsigned)(g << 5)) + abuf * A_BYTES) + t * A_TERM);
+    };
+    auto w_addr = [&](unsigned buf, int t, int g, int nb) -> const u32x4 * {
+        return reinterpret_cast<const u32x4 *>(ldsb + B_BASE + buf * B_BYTES + lane * 16 + (((t * KG + g) * NBT + nb0 + nb) * 1024));
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+
+    // ---- prologue: A(slice 0) and B stages 0..LEAD-1 of the first tile ----
+    tile_offsets(tile);
+#pragma unroll
+    for (int jj = 0; jj < APW; jj++) dma_a(0, 0, jj);
+#pragma unroll
+    for (int t = 0; t < LEAD; t++)
+#pragma unroll
+        for (int jb = 0; jb < BPW; jb++) dma_b(0, t, t, jb);
+    W2XC_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+
+    unsigned gs = 0;      // ring slot of the current stage
+    unsigned abuf = 0;    // A buffer of the current slice
+    int sl = 0;
+    bool epi_stores = false;   // an interior-tile epilogue (NST stores) directly precedes the current slice
+    u32x4 x_cur[T][MB], w_cur[T][NB];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) x_cur[t][mb] = *x_addr(0, t, mb, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) w_cur[t][nb] = *w_addr(0, t, 0, nb);
+    }
+
+    for (;;) {
+        // what the A pieces issued during this slice fetch: the next slice, or the next tile's first
+        const bool last_slice = (sl == NSL - 1);
+        unsigned a_add = (unsigned)(sl + 1) * gs16;
+        if (last_slice) {
+            tile_offsets(tile + per < chunk_end ? tile + per : tile);
+            a_add = 0;
+        }
+        const int sl_next = last_slice ? 0 : sl + 1;
+
+        static_for<0, 9>([&](auto TAP) {
+            constexpr int tap = decltype(TAP)::value;
+            constexpr int tapL = (tap + LEAD) % 9;
+            const int slL = (tap + LEAD < 9) ? sl : sl_next;
+            const unsigned buf = gs, bufL = gs + LEAD >= RING ? gs + LEAD - RING : gs + LEAD, buf1 = gs + 1 >= RING ? 0 : gs + 1;
+            // A pieces of the next slice: ka(t) = ceil-spread of APW over taps 0..LASTA, at most 2 per tap
+            constexpr int ja0 = ka_before<APW, LASTA>(tap);
+            static_for<0, KG>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                // One step = M MFMAs on k-group g; the other instructions are pinned into MFMA shadows:
+                // the DMAs of this step first, then the fragment reads of the NEXT step (the last step of a
+                // stage reads the next stage's first fragments, complete since the previous barrier).
+                // Filler f sits behind MFMA (f * D) / F, D = M - LATE: the last LATE MFMAs cover the LDS latency.
+                constexpr int M = NP * MB * NB, R = T * (MB + NB);
+                constexpr int n_a = (g == 0) ? ka<APW, LASTA>(tap) : 0;
+                constexpr int n_b = g < BPW ? (BPW - g + KG - 1) / KG : 0;
+                constexpr int F = n_a + n_b + R;
+                constexpr int LATE = W2XC_SPLIT_LATE < M / 2 ? W2XC_SPLIT_LATE : M / 2;
+                constexpr int D = M - LATE;
+                constexpr bool wrap = (g == KG - 1);
+                constexpr int tap_n = wrap ? (tap + 1) % 9 : tap, g_n = wrap ? 0 : g + 1;
+                const unsigned abuf_n = (wrap && tap == 8) ? (abuf ^ 1u) : abuf;
+                const unsigned bbuf_n = wrap ? buf1 : buf;
+                u32x4 x_nxt[T][MB], w_nxt[T][NB];
+                static_for<0, M>([&](auto MI) {
+                    constexpr int m = decltype(MI)::value;            // MFMA index in the step
+                    constexpr int pi = m / (MB * NB), mb = (m / NB) % MB, nb = m % NB;
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, w_cur[Prod<T>::b(pi)][nb]),
+                        __builtin_bit_cast(bf16x8, x_cur[Prod<T>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
+                    constexpr int f0 = m < D ? (m * F + D - 1) / D : F;
+                    constexpr int f1 = m < D ? (((m + 1) * F + D - 1) / D < F ? ((m + 1) * F + D - 1) / D : F) : F;
+                    static_for<f0, f1>([&](auto FI) {
+                        constexpr int f = decltype(FI)::value;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (f < n_a) {
+#ifndef W2XC_X_NOA
+                            dma_a(a_add, abuf ^ 1u, ja0 + f);
+#endif
+                        } else if constexpr (f < n_a + n_b) {
+#ifndef W2XC_X_NOB
+                            dma_b(slL, tapL, bufL, g + (f - n_a) * KG);
+#endif
+                        } else {
+                            constexpr int code = read_decode<T, MB, NB>(f - n_a - n_b);
+                            constexpr int t = (code / 10) % 10, u = code % 10;
+                            if constexpr (code < 100) x_nxt[t][u] = *x_addr(abuf_n, t, u, tap_n, g_n);
+                            else w_nxt[t][u] = *w_addr(bbuf_n, t, g_n, u);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) x_cur[t][mb] = x_nxt[t][mb];
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) w_cur[t][nb] = w_nxt[t][nb];
+                }
+            });
+            // stage boundary: B(t+2) -- issued LOOK stages ago -- must have landed; the only younger transfers
+            // are the ones issued since (vmcnt retires in order).  For the first LOOK stages after an interior
+            // epilogue the NST stores are younger than B(t+2) too and are counted in rather than drained.
+            {
+                constexpr int n_dma = ka_window<APW, LASTA>(tap, LOOK) + LOOK * BPW;
+                if (tap < LOOK && sl == 0 && epi_stores) wait_vmcnt_n(n_dma + NST);
+                else wait_vmcnt_n(n_dma);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            gs = buf1;
+        });
+        abuf ^= 1u;
+        epi_stores = false;
+
+        if (last_slice) {
+            // ---- epilogue: bias + LeakyReLU in fp32, split into OT bf16 terms (or fp32), NHWC stores.
+            //      C/D: lane&31 = pixel, channel = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+            const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+            const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+            const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
+            // fp32 out: NHWC.  Term planes: channel-group blocked, element (t, c, y, x) at
+            //   t*ts + (c / SLC)*gs + y*rs + x*SLC + c % SLC   (the layout the next layer's A tiles stream from)
+            const long long obase = OT == 0 ? (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * COUT + nb0 * 32 + 4 * kk
+                                            : (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * SLC;
+            auto oofs = [&](int mb, int nb, int i) -> long long {   // element offset of channels (nb0+nb)*32 + 8i + 4kk .. +3
+                if (OT == 0) return obase + (long long)mb * d.out_rs + nb * 32 + 8 * i;
+                const int c = (nb0 + nb) * 32 + 8 * i + 4 * kk;
+                return obase + (long long)mb * d.out_rs + (long long)(c / SLC) * d.out_gs + c % SLC;
+            };
+            if (interior) {
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float s = acc[mb][nb][4 * i + e] + bv[nb][4 * i + e];
+                                v[e] = fmaxf(s, 0.1f * s);
+                                acc[mb][nb][4 * i + e] = 0.0f;
+                            }
+                            store_terms<OT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
+                        }
+                epi_stores = true;
+            } else {
+                const bool xin = ox0 + li < d.out_w;
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) {
+                    const bool in = xin && (oy0 + wm * MB + mb < d.out_h);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float s = acc[mb][nb][4 * i + e] + bv[nb][4 * i + e];
+                                v[e] = fmaxf(s, 0.1f * s);
+                                acc[mb][nb][4 * i + e] = 0.0f;
+                            }
+                            if (in) store_terms<OT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
+                        }
+                }
+            }
+            tile += per;
+            if (tile >= chunk_end) break;
+            sl = 0;
+        } else {
+            sl++;
+        }
+    }
+    W2XC_WAIT_VMCNT(0);   // drain the speculative DMAs before the LDS is released
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3_first_split: conv3x3_first (K = 9*CIN on v_mfma_f32_32x32x2_f32, fp32 planar input with the
+// clamp-to-edge pad and the optional nearest-neighbour 2x folded into the LDS fill) with the operands
+// swapped, so that a lane holds 4 consecutive channels of one pixel and stores OT term planes directly.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int NBT, int OT>
+__global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int tiles_x, int ntiles)
+{
+    constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2;
+    constexpr int OSLC = OT == 3 ? 16 : 32;           // channel-group size of the consumer (16 * its KG)
+    constexpr int K = 9 * CIN, S = (K + 1) / 2;
+    constexpr int COUT = 32 * NBT;
+    __shared__ float lds[CIN * HH * HW];
+
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (int idx = threadIdx.x; idx < CIN * HH * HW; idx += 256) {
+        const int c = idx / (HH * HW), p = idx - c * (HH * HW);
+        const int py = p / HW, px = p - py * HW;
+        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;
+        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;
+        lds[idx] = d.in[(long long)c * d.in_cs + (long long)gy * d.in_rs + (long long)gx * d.in_ps];
+    }
+    __syncthreads();
+
+    const int kk = lane >> 5, i = lane & 31;
+    float a[MB][S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int off0 = (k0 / 9) * (HH * HW) + ((k0 % 9) / 3) * HW + (k0 % 9) % 3;
+        const int off1 = k1 < K ? (k1 / 9) * (HH * HW) + ((k1 % 9) / 3) * HW + (k1 % 9) % 3 : 0;
+        const int off = kk ? off1 : off0;
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) a[mb][s] = lds[(wave * MB + mb) * HW + i + off];
+    }
+
+    const int x = ox0 + i;
+#pragma unroll 1
+    for (int nb = 0; nb < NBT; nb++) {
+        float b[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) b[s] = d.wpk[(nb * S + s) * 64 + lane];
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mb][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[mb][s], acc[mb], 0, 0, 0);   // rows = channels, columns = pixels
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+            const int y = oy0 + wave * MB + mb;
+            if (y < d.out_h && x < d.out_w) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e] + d.bias[nb * 32 + 8 * q + 4 * kk + e]);
+                    const int c = nb * 32 + 8 * q + 4 * kk;      // blocked term planes (see conv3x3_split)
+                    store_terms<OT>(d.out, (long long)(c / OSLC) * d.out_gs + (long long)y * d.out_rs + (long long)x * OSLC + c % OSLC, d.out_ts,
+                                    v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+int w2xc_split_kg(int terms, int cin) { (void)cin; return terms == 3 ? 1 : 2; }
+
+size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
+
+// wpk[tap][slice][term][g][nb][lane][8] (bf16) = term `term` of W[32*nb + (lane&31)][slice*16*KG + 16*g + 8*(lane>>5) + e][tap]
+void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst)
+{
+    auto bf = [](float f) -> unsigned short {
+        unsigned u;
+        memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    };
+    auto bf2f = [](unsigned short h) -> float {
+        const unsigned u = (unsigned)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    const int kg = w2xc_split_kg(terms, cin), nsl = cin / (16 * kg), nbt = cout / 32;
+    unsigned short *d16 = static_cast<unsigned short *>(dst);
+    for (int tap = 0; tap < 9; tap++)
+        for (int sl = 0; sl < nsl; sl++)
+            for (int nb = 0; nb < nbt; nb++)
+                for (int g = 0; g < kg; g++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            const int o = nb * 32 + (lane & 31), c = sl * 16 * kg + 16 * g + 8 * (lane >> 5) + e;
+                            float r = w[((size_t)o * cin + c) * 9 + tap];
+                            for (int t = 0; t < terms; t++) {
+                                const unsigned short h = bf(r);
+                                d16[((((((size_t)tap * nsl + sl) * terms + t) * kg + g) * nbt + nb) * 64 + lane) * 8 + e] = h;
+                                r -= bf2f(h);
+                            }
+                        }
+}
+
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING>
+static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+    constexpr int NW = WM * WN;
+    constexpr int A_PIECES = T * 352 * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
+    constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024);
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING>;
+    static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev < 64) attr_done.fetch_or(1ull << dev);
+    }
+    int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
+    if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
+    return hipGetLastError();
+}
+
+// tile shapes per (cin, cout): 4 waves, one per SIMD
+template <int T, int OT>
+static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
+{
+    constexpr int KGA = T == 3 ? 1 : 2, KGB = KGA;     // k-groups (16 channels) per slice = per channel group of the layout
+    constexpr int RG = T == 3 ? 6 : 4;
+    switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
+    //                                CIN  COUT  MB NB WM WN
+    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KGB, RG>(d, stream);
+    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KGB, RG>(d, stream);
+    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KGB, RG>(d, stream);
+    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KGA, RG>(d, stream);
+    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KGA, RG>(d, stream);
+    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KGA, RG>(d, stream);
+    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KGA, RG>(d, stream);
+    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KGA, RG>(d, stream);
+#endif
+    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KGA, RG>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
+    switch (d.terms * 10 + d.out_terms) {
+    case 10: return launch_split_t<1, 0>(d, stream);
+    case 11: return launch_split_t<1, 1>(d, stream);
+    case 20: return launch_split_t<2, 0>(d, stream);
+    case 22: return launch_split_t<2, 2>(d, stream);
+    case 30: return launch_split_t<3, 0>(d, stream);
+    case 33: return launch_split_t<3, 3>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int OT>
+static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+#define W2XC_FS(CIN, NBT) hipLaunchKernelGGL((conv3x3_first_split<CIN, NBT, OT>), dim3(ntiles), dim3(256), 0, stream, d, tiles_x, ntiles); break
+    switch (d.cin * 1000 + d.cout) {
+    case 1032:  W2XC_FS(1, 1);
+    case 1064:  W2XC_FS(1, 2);
+    case 1128:  W2XC_FS(1, 4);
+    case 3032:  W2XC_FS(3, 1);
+    case 3064:  W2XC_FS(3, 2);
+    case 3128:  W2XC_FS(3, 4);
+    default: return hipErrorInvalidValue;
+    }
+#undef W2XC_FS
+    return hipGetLastError();
+}
+
+hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    switch (d.out_terms) {
+    case 1: return launch_first_split_t<1>(d, stream);
+    case 2: return launch_first_split_t<2>(d, stream);
+    case 3: return launch_first_split_t<3>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
