@@ -126,9 +126,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic; NOT the headline number: the reference "
-                         "computes in fp32 and `value` is only valid for the default)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x2", "bf16x3"],
+                    help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic); bf16x2 / bf16x3 = split-bf16 (fp32 values as "
+                         "2 / 3 bf16 terms on the bf16 MFMA).  NOT the headline number: the reference computes in fp32 "
+                         "and `value` is only the BASELINE metric for the default")
     ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane", "image_u8"],
                     help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
                          "ranks (BASELINE.json configs[2] with --width 8192 --height 8192): strong scaling")
@@ -172,7 +173,8 @@ def main():
     H, W = plane.shape
     stream = torch.cuda.current_stream()
     opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows,
-                          precision=w2xc.PRECISION_BF16 if args.precision == "bf16" else w2xc.PRECISION_FP32)
+                          precision={"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2,
+                                     "bf16x3": w2xc.PRECISION_BF16X3}[args.precision])
     if args.workload == "image_u8":
         # N2: uint8 RGB frame in HBM -> uint8 2x frame in HBM (colour conversion, bicubic U/V, CNN on Y, back to uint8)
         rgb = np.random.default_rng(2 + rank).integers(0, 256, size=(args.height, args.width, 3), dtype=np.uint8)
@@ -241,7 +243,9 @@ def main():
         dom_ms = layer_ms[dom] / dom_launches
         bands = nbands[dom]
         dom_flops = flops_layer[dom] / bands
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # split-bf16: every algorithmic multiply-add is 3 (bf16x2) or 6 (bf16x3) bf16 MFMA products
+        products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6}[args.precision]
+        achieved = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         per_layer = []
         for l in range(n_layers):
             ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
@@ -256,7 +260,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 activations/weights between layers, f32 accumulate (not the headline precision)",
+            "dtype": {"fp32": "f32",
+                      "bf16": "bf16 activations/weights between layers, f32 accumulate (not the headline precision)",
+                      "bf16x2": "f32 values as 2 bf16 terms (3 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision",
+                      "bf16x3": "f32 values as 3 bf16 terms (6 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU): " if args.workload == "image_u8" else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
                                    "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
@@ -269,7 +276,7 @@ def main():
                          "traffic": pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
                          if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else None,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
-                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops},
+                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops, "mfma_products_per_fma": products},
             "layers": per_layer,
             "output_finite": ok,
         }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX>
+"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX> [fp32|bf16x2|bf16x3]
 Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries:
   PREFIX_kernel_stats.csv  (rocprofv3 --kernel-trace --stats)
   PREFIX_pmc_summary.txt   (per-kernel means of every PMC counter)
@@ -8,6 +8,9 @@ FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE reports 1/2 of wide streaming
 (MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024."""
 import csv, json, os, shutil, subprocess, sys
 base, prefix = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3}[prec]
+PRODUCTS = {0: 1, 2: 3, 3: 6}[T]
 H, W, NL = 2160, 3840, 7
 PLANES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)]
 shutil.copy(base + "trace/trace_kernel_stats.csv", prefix + "_kernel_stats.csv")
@@ -20,10 +23,13 @@ def mean_counter(path, sub, counter):
     return sum(v) / len(v) if v else None
 
 stats = {r["Name"]: r for r in csv.DictReader(open(base + "trace/trace_kernel_stats.csv"))}
-out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (tools/profile.sh)",
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline%s (tools/profile.sh)" % ("" if T == 0 else " --precision " + prec),
        "note": __doc__.split("FETCH_SIZE", 1)[1].strip().replace("\n", " "), "kernels": {}}
 for k, (cin, cout) in enumerate(PLANES, 1):
-    sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
+    if T == 0:
+        sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
+    else:
+        sub = ("conv3x3_first_split<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_split<%d, %d," % (cin, cout))
     names = [n for n in stats if sub in n and n.startswith("void conv3x3")]
     if not names:
         continue
@@ -32,9 +38,13 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     avg_ns = float(stats[name]["AverageNs"])
     fetch = mean_counter(pmcs[0], sub, "FETCH_SIZE"); write = mean_counter(pmcs[1], sub, "WRITE_SIZE")
     rd, wr = 2 * fetch * 1024, write * 1024
-    alg = (cin + cout) * 4 * px
+    # bytes per element: fp32 planes at the caller's boundary and into the last layer, T bf16 terms in between
+    in_bpe = 4 if (T == 0 or k == 1 or k == NL) else 2 * T
+    out_bpe = 4 if (T == 0 or k >= NL - 1) else 2 * T
+    alg = (cin * in_bpe + cout * out_bpe) * px
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px,
          "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,
+         "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
          "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}
     grbm = mean_counter(pmcs[3], sub, "GRBM_GUI_ACTIVE"); busy = mean_counter(pmcs[2], sub, "SQ_VALU_MFMA_BUSY_CYCLES")

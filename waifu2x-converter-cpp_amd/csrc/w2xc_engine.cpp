@@ -151,18 +151,10 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
     return r;
 }
 
-// bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline).
-// W2XC_PRECISION_BF16 runs through it as the one-term case when W2XC_BF16_PIPE=split (tuning aid).
+// bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline)
 int split_terms(const w2xc_opts &o)
 {
-    if (o.precision == W2XC_PRECISION_BF16X2) return 2;
-    if (o.precision == W2XC_PRECISION_BF16X3) return 3;
-    if (o.precision == W2XC_PRECISION_BF16) {
-        static int v = -1;
-        if (v < 0) { const char *e = getenv("W2XC_BF16_PIPE"); v = (e && !strcmp(e, "split")) ? 1 : 0; }
-        return v;
-    }
-    return 0;
+    return o.precision == W2XC_PRECISION_BF16X2 ? 2 : o.precision == W2XC_PRECISION_BF16X3 ? 3 : 0;
 }
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
@@ -279,7 +271,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         if (rc) return rc;
     }
     if (kind == W2XC_K_MID_SPLIT) {
-        if (d.terms < 1 || d.terms > 3) return fail(W2XC_ERR_ARG, "bad term count %d", d.terms);
+        if (d.terms < 2 || d.terms > 3) return fail(W2XC_ERR_ARG, "bad term count %d", d.terms);
         if (!dl.w_split[d.terms]) {
             std::vector<float> pk((w2xc_split_packed_bytes(d.cin, d.cout, d.terms) + 3) / 4);
             w2xc_split_pack(d.cin, d.cout, d.terms, m->layers[l].w.data(), pk.data());

@@ -5,14 +5,16 @@
 //     a = a0 + a1 (+ a2),  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (round to nearest even)
 //     a*b ~= sum of the NP largest term products, accumulated in fp32 inside the matrix core
 //
-//     T = 1  (W2XC_PRECISION_BF16)     1 product   8-bit operands
+//     T = 1                            1 product   8-bit operands (template only: W2XC_PRECISION_BF16 has its own
+//                                                  kernels in w2xc_kernels.hip, this pipeline measured no faster)
 //     T = 2  (W2XC_PRECISION_BF16X2)   3 products  a0b0 + a0b1 + a1b0:            ~16-bit operands, |err| ~ 2^-17 |ab|
 //     T = 3  (W2XC_PRECISION_BF16X3)   6 products  + a1b1 + a0b2 + a2b0:          ~24-bit operands, |err| ~ 2^-24 |ab|,
 //                                                                                  i.e. the error level of an fp32 FMA chain
 //
-// Activations between the layers are T planes of NHWC bf16 ("term planes", `ts` elements apart); the producer's
-// epilogue does the split once per element, so the consumer streams ready-made bf16 fragments with LDS-DMA exactly
-// like conv3x3_mfma2 streams fp32 ones.  The mid layer that feeds the last layer writes plain fp32 NHWC, so
+// Activations between the layers are T bf16 "term planes" (`ts` elements apart), each channel-group blocked:
+// element (c, y, x) at (c / G)*gs + y*rs + x*G + c % G with G = 16*KG = the consumer's K-slice, so the halo tile
+// of one (slice, term) is contiguous per row.  The producer's epilogue does the split once per element, so the
+// consumer streams ready-made bf16 fragments with LDS-DMA exactly like conv3x3_mfma2 streams fp32 ones.  The mid layer that feeds the last layer writes plain fp32 NHWC, so
 // conv3x3_last is used unchanged.
 //
 //   conv3x3_split        cin, cout in {32,64,128}: persistent workgroups (one per CU), tile = 8 rows x 32 pixels x COUT.
@@ -334,13 +336,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                         constexpr int f = decltype(FI)::value;
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (f < n_a) {
-#ifndef W2XC_X_NOA
                             dma_a(a_add, abuf ^ 1u, ja0 + f);
-#endif
                         } else if constexpr (f < n_a + n_b) {
-#ifndef W2XC_X_NOB
                             dma_b(slL, tapL, bufL, g + (f - n_a) * KG);
-#endif
                         } else {
                             constexpr int code = read_decode<T, MB, NB>(f - n_a - n_b);
                             constexpr int t = (code / 10) % 10, u = code % 10;
@@ -576,25 +574,26 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// tile shapes per (cin, cout): 4 waves, one per SIMD
+// tile shapes per (cin, cout): 4 waves, one per SIMD (8 waves, two per SIMD, measured within 2 %: the big
+// layers run against the power limit -- the shader clock sits at ~1.8 GHz under the dense bf16 MFMA stream)
 template <int T, int OT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
-    constexpr int KGA = T == 3 ? 1 : 2, KGB = KGA;     // k-groups (16 channels) per slice = per channel group of the layout
+    constexpr int KG = T == 3 ? 1 : 2;     // k-groups (16 channels) per slice = per channel group of the layout
     constexpr int RG = T == 3 ? 6 : 4;
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                CIN  COUT  MB NB WM WN
-    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KGB, RG>(d, stream);
-    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KGB, RG>(d, stream);
-    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KGB, RG>(d, stream);
-    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KGA, RG>(d, stream);
-    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KGA, RG>(d, stream);
-    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KGA, RG>(d, stream);
-    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KGA, RG>(d, stream);
-    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KGA, RG>(d, stream);
+    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
+    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
+    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
+    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
+    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
+    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
+    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
+    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
 #endif
-    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KGA, RG>(d, stream);
+    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -604,8 +603,6 @@ hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
     switch (d.terms * 10 + d.out_terms) {
-    case 10: return launch_split_t<1, 0>(d, stream);
-    case 11: return launch_split_t<1, 1>(d, stream);
     case 20: return launch_split_t<2, 0>(d, stream);
     case 22: return launch_split_t<2, 2>(d, stream);
     case 30: return launch_split_t<3, 0>(d, stream);
@@ -637,7 +634,6 @@ hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     switch (d.out_terms) {
-    case 1: return launch_first_split_t<1>(d, stream);
     case 2: return launch_first_split_t<2>(d, stream);
     case 3: return launch_first_split_t<3>(d, stream);
     default: return hipErrorInvalidValue;
