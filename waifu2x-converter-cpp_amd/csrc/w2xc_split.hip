@@ -33,6 +33,9 @@
 #include <atomic>
 #include <type_traits>
 
+#ifndef W2XC_SPLIT_T
+#error "compile with -DW2XC_SPLIT_T=2 or -DW2XC_SPLIT_T=3 (one object per term count, see the Makefile)"
+#endif
 #ifndef W2XC_SPLIT_LATE
 #define W2XC_SPLIT_LATE 4   // MFMAs kept after the last fragment read of a step
 #endif
@@ -512,6 +515,7 @@ __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int t
 // ================================================================================================
 // host side
 // ================================================================================================
+#if W2XC_SPLIT_T == 3   // shared host code lives in one object
 int w2xc_split_kg(int terms, int cin) { (void)cin; return terms == 3 ? 1 : 2; }
 
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
@@ -548,6 +552,8 @@ void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst)
                             }
                         }
 }
+
+#endif
 
 template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING>
 static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
@@ -598,19 +604,8 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
     }
 }
 
-hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
-{
-    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
-    switch (d.terms * 10 + d.out_terms) {
-    case 20: return launch_split_t<2, 0>(d, stream);
-    case 22: return launch_split_t<2, 2>(d, stream);
-    case 30: return launch_split_t<3, 0>(d, stream);
-    case 33: return launch_split_t<3, 3>(d, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-
+// One object file per term count (Makefile: -DW2XC_SPLIT_T=2 / 3) so the two sets of instantiations compile
+// in parallel; the T = 3 object also carries the shared host code below.
 template <int OT>
 static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -630,12 +625,28 @@ static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream
     return hipGetLastError();
 }
 
+#if W2XC_SPLIT_T == 2
+hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
+{
+    return d.out_terms == 2 ? launch_split_t<2, 2>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0>(d, stream) : hipErrorInvalidValue;
+}
+hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2>(d, stream); }
+#else
+hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream);
+
+hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
+    if (d.terms == 2) return w2xc_launch_split_mid_2(d, stream);
+    if (d.terms != 3) return hipErrorInvalidValue;
+    return d.out_terms == 3 ? launch_split_t<3, 3>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0>(d, stream) : hipErrorInvalidValue;
+}
+
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    switch (d.out_terms) {
-    case 2: return launch_first_split_t<2>(d, stream);
-    case 3: return launch_first_split_t<3>(d, stream);
-    default: return hipErrorInvalidValue;
-    }
+    return d.out_terms == 2 ? w2xc_launch_split_first_2(d, stream) : d.out_terms == 3 ? launch_first_split_t<3>(d, stream) : hipErrorInvalidValue;
 }
+#endif
