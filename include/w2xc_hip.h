@@ -53,7 +53,7 @@ typedef struct w2xc_model w2xc_model;
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */
-    int      precision;       /* W2XC_PRECISION_*                                                    */
+    int      precision;       /* W2XC_PRECISION_*  (opts == NULL: the env var W2XC_PRECISION, default fp32)  */
     int      kernel;          /* W2XC_KERNEL_*                                                       */
     int      device;          /* device-pointer entry points: HIP device ordinal, -1 = current      */
     unsigned device_mask;     /* host-pointer entry points: bit i = use device i; 0 = all devices   */

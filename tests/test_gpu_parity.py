@@ -582,14 +582,15 @@ def test_cli_shell_end_to_end(gpu, models_dir, tmp_path):
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1
 
 
-def test_mfma2_race_screen(gpu, scale_layers):
-    """conv3x3_mfma2 orders its LDS-DMA transfers with hand-counted vmcnt + raw barriers.  It is deterministic by
+@pytest.mark.parametrize("precision", ["fp32", "bf16x2", "bf16x3"])
+def test_mfma2_race_screen(gpu, scale_layers, precision):
+    """conv3x3_mfma2 (and conv3x3_split, same protocol) orders its LDS-DMA transfers with hand-counted vmcnt + raw barriers.  It is deterministic by
     construction, so a protocol error (a transfer landing late, a ring slot overwritten early) would surface as
     run-to-run differences, most likely under memory load: repeat on the same input with and without a
     competing HBM stream, demand bit-identical planes (tools/stress_determinism.py is the long form)."""
     torch = pytest.importorskip("torch")
     ms = gpu._ModelSet.from_layers(scale_layers)
-    o = gpu.make_opts(device=0)
+    o = gpu.make_opts(device=0, precision={"fp32": gpu.PRECISION_FP32, "bf16x2": gpu.PRECISION_BF16X2, "bf16x3": gpu.PRECISION_BF16X3}[precision])
     st = torch.cuda.current_stream()
     side = torch.cuda.Stream()
     junk = torch.rand(4096, 4096, device="cuda")
@@ -629,3 +630,40 @@ def test_host_multi_band_path(gpu, scale_layers, tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_default_precision_from_environment(gpu, scale_layers, tmp_path):
+    """callers that pass no w2xc_opts (the C++ adapter behind the unmodified CLI) get W2XC_PRECISION from the
+    environment: the bf16x3 run must equal an explicit BF16X3 call bit for bit, and differ from fp32."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
+        "x = np.random.default_rng(4).random((64, 96), dtype=np.float32)\n"
+        "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert(x, opts=w.make_opts(precision=w.PRECISION_BF16X3)),\n"
+        "                               ms.convert(x, opts=w.make_opts(precision=w.PRECISION_FP32))]))\n" % ROOT)
+    f = str(tmp_path / "o.npy")
+    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_PRECISION="bf16x3"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    default, x3, fp32 = np.load(f)
+    assert np.array_equal(default, x3) and not np.array_equal(default, fp32)
+
+
+def test_cli_shell_precision_flag(gpu, models_dir, tmp_path):
+    """tools/w2xc_cli.py --precision bf16x3: same picture as the fp32 run up to single LSBs"""
+    import subprocess, sys
+    from PIL import Image
+    from conftest import ROOT
+    rgb = np.random.default_rng(13).integers(0, 256, (24, 28, 3), dtype=np.uint8)
+    src = tmp_path / "in.png"
+    Image.fromarray(rgb).save(src)
+    outs = []
+    for prec in ("fp32", "bf16x3"):
+        o = tmp_path / ("out_%s.png" % prec)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "w2xc_cli.py"), "-i", str(src), "-o", str(o), "-m", "scale",
+                            "--model_dir", models_dir, "--precision", prec], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.asarray(Image.open(o)).astype(np.int16))
+    assert outs[0].shape == (48, 56, 3) and np.abs(outs[0] - outs[1]).max() <= 1

@@ -147,6 +147,18 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
         size_t n = o->struct_size > 0 && (size_t)o->struct_size < sizeof(w2xc_opts) ? (size_t)o->struct_size : sizeof(w2xc_opts);
         memcpy(&r, o, n);
         r.struct_size = (int)sizeof(w2xc_opts);
+    } else {
+        // callers that pass no options (the C++ adapter behind the reference's CLI): the default precision can
+        // be switched without recompiling -- W2XC_PRECISION = fp32 | bf16x3 | bf16x2 | bf16
+        static const int env_prec = [] {
+            const char *e = getenv("W2XC_PRECISION");
+            if (!e) return W2XC_PRECISION_FP32;
+            if (!strcmp(e, "bf16x3")) return W2XC_PRECISION_BF16X3;
+            if (!strcmp(e, "bf16x2")) return W2XC_PRECISION_BF16X2;
+            if (!strcmp(e, "bf16")) return W2XC_PRECISION_BF16;
+            return W2XC_PRECISION_FP32;
+        }();
+        r.precision = env_prec;
     }
     return r;
 }
