@@ -126,9 +126,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x2", "bf16x3"],
-                    help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic); bf16x2 / bf16x3 = split-bf16 (fp32 values as "
-                         "2 / 3 bf16 terms on the bf16 MFMA).  NOT the headline number: the reference computes in fp32 "
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x2", "bf16x3", "fp16x2"],
+                    help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic); bf16x2 / bf16x3 / fp16x2 = split products (fp32 values "
+                         "as 2 / 3 bf16 terms or 2 fp16 terms on the 16-bit MFMAs).  NOT the headline number: the reference computes in fp32 "
                          "and `value` is only the BASELINE metric for the default")
     ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane", "image_u8"],
                     help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
@@ -174,7 +174,7 @@ def main():
     stream = torch.cuda.current_stream()
     opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows,
                           precision={"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2,
-                                     "bf16x3": w2xc.PRECISION_BF16X3}[args.precision])
+                                     "bf16x3": w2xc.PRECISION_BF16X3, "fp16x2": w2xc.PRECISION_FP16X2}[args.precision])
     if args.workload == "image_u8":
         # N2: uint8 RGB frame in HBM -> uint8 2x frame in HBM (colour conversion, bicubic U/V, CNN on Y, back to uint8)
         rgb = np.random.default_rng(2 + rank).integers(0, 256, size=(args.height, args.width, 3), dtype=np.uint8)
@@ -244,7 +244,7 @@ def main():
         bands = nbands[dom]
         dom_flops = flops_layer[dom] / bands
         # split-bf16: every algorithmic multiply-add is 3 (bf16x2) or 6 (bf16x3) bf16 MFMA products
-        products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6}[args.precision]
+        products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "fp16x2": 3}[args.precision]
         achieved = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         per_layer = []
         for l in range(n_layers):
@@ -263,6 +263,7 @@ def main():
             "dtype": {"fp32": "f32",
                       "bf16": "bf16 activations/weights between layers, f32 accumulate (not the headline precision)",
                       "bf16x2": "f32 values as 2 bf16 terms (3 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision",
+                      "fp16x2": "f32 values as 2 fp16 terms (3 fp16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision",
                       "bf16x3": "f32 values as 3 bf16 terms (6 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU): " if args.workload == "image_u8" else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
@@ -280,6 +281,29 @@ def main():
             "layers": per_layer,
             "output_finite": ok,
         }
+        if world == 1 and args.precision == "fp32" and args.workload == "scale2x_1080p":
+            # the opt-in precisions on the same resident plane, right after the timed region (3 steps each): their
+            # time and their distance from the fp32 result just measured.  Informational -- `value` above is fp32.
+            try:
+                other = {}
+                ref = d_out.clone()
+                rng = float(ref.abs().max().item())
+                for name, prec in (("fp16x2", w2xc.PRECISION_FP16X2), ("bf16x3", w2xc.PRECISION_BF16X3),
+                                   ("bf16x2", w2xc.PRECISION_BF16X2), ("bf16", w2xc.PRECISION_BF16)):
+                    o2 = w2xc.make_opts(device=dev_index, band_rows=args.band_rows, precision=prec)
+                    run = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o2)
+                    run()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        run()
+                    torch.cuda.synchronize()
+                    ms_p = (time.perf_counter() - t1) / 3 * 1e3
+                    other[name] = {"ms_per_step": round(ms_p, 3), "Mpix_s": round(in_px / ms_p / 1e3, 2),
+                                   "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
+                out["other_precisions"] = other
+            except Exception as e:   # never let the side measurement break the headline line
+                out["other_precisions"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(layers, plane, args.cpu_budget)
             out["speedup_vs_cpu"] = round(value / world / out["cpu_baseline"]["value"], 1)

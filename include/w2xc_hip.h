@@ -47,6 +47,11 @@ typedef struct w2xc_model w2xc_model;
 #define W2XC_PRECISION_BF16X3 3 /* as above with 3 terms (~24 mantissa bits) and 6 products: the error level
                                  * of an fp32 FMA chain at 2.7x the fp32 MFMA rate of CDNA4.  First / last
                                  * layer arithmetic stays fp32 MFMA in both.  Tolerances in DESIGN.md 4.   */
+#define W2XC_PRECISION_FP16X2 4 /* split into 2 fp16 terms (~22 mantissa bits), 3 products on the fp16 MFMA: the
+                                 * speed of BF16X2 at nearly the accuracy of BF16X3.  fp16 has 5 exponent bits:
+                                 * weights are pre-scaled per layer by a power of two (exact), activations of
+                                 * layers 1..n-2 saturate at +-65504 and carry 2^-25 ABSOLUTE precision below
+                                 * 2^-3 -- meant for image planes in [0, 1].                   */
 
 #define W2XC_KERNEL_AUTO    0   /* MFMA implicit-GEMM where the layer shape allows                 */
 #define W2XC_KERNEL_DIRECT  1   /* reference-ordered direct conv on VALU (bit-exact vs the oracle) */

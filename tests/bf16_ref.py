@@ -30,22 +30,25 @@ def convert_bf16_emulated(layers, plane):
 PRODUCTS = {1: [(0, 0)], 2: [(1, 0), (0, 1), (0, 0)], 3: [(1, 1), (2, 0), (0, 2), (1, 0), (0, 1), (0, 0)]}   # (activation term, weight term)
 
 
-def _split(t, terms):
-    """fp32 tensor -> list of `terms` bf16-valued float64 tensors: a0 = bf16(a), a1 = bf16(a - a0), ... (RNE)."""
+def _split(t, terms, dtype=torch.bfloat16):
+    """fp32 tensor -> list of `terms` 16-bit-valued float64 tensors: a0 = rnd(a), a1 = rnd(a - a0), ... (RNE)."""
     r = t.to(torch.float32)
     out = []
     for _ in range(terms):
-        h = r.to(torch.bfloat16).to(torch.float32)
+        h = r.to(dtype).to(torch.float32)
         out.append(h.to(torch.float64))
         r = r - h          # exact in fp32
     return out
 
 
-def convert_split_emulated(layers, plane, terms, n_in=1):
-    """Dataflow of the split-bf16 pipeline with float64 accumulation: fp32 first layer; every mid layer
-    (cin, cout in {32,64,128}, not first) sums PRODUCTS[terms] of the bf16 terms of its fp32 input and
-    weights; fp32 last layer.  `plane` is (h, w) or (n_in, h, w); returns all output planes."""
+def convert_split_emulated(layers, plane, terms, n_in=1, fp16=False):
+    """Dataflow of the split pipeline with float64 accumulation: fp32 first layer; every mid layer
+    (cin, cout in {32,64,128}, not first) sums PRODUCTS[terms] of the 16-bit terms of its fp32 input and
+    weights; fp32 last layer.  fp16=True (W2XC_PRECISION_FP16X2): fp16 terms, activations clamped to +-65504,
+    weights scaled by the power of two that puts max|w| into [2^14, 2^15) and the sum scaled back.
+    `plane` is (h, w) or (n_in, h, w); returns all output planes."""
     n = len(layers)
+    dt = torch.float16 if fp16 else torch.bfloat16
     x = np.ascontiguousarray(plane, dtype=np.float32)
     t = torch.from_numpy(x).reshape(1, n_in, x.shape[-2], x.shape[-1])
     t = F.pad(t.to(torch.float64), (n, n, n, n), mode="replicate").to(torch.float32)
@@ -54,12 +57,17 @@ def convert_split_emulated(layers, plane, terms, n_in=1):
         bias = torch.from_numpy(b.astype(np.float32)).to(torch.float64)
         wt = torch.from_numpy(w)
         if k > 0 and mid(nin) and mid(nout):
-            xs, ws = _split(t, terms), _split(wt, terms)
+            scale = 1.0
+            if fp16:
+                mx = float(np.abs(w).max())
+                scale = float(2.0 ** (15 - np.frexp(np.float32(mx))[1])) if mx > 0 else 1.0
+                t = t.clamp(-65504.0, 65504.0)
+            xs, ws = _split(t, terms, dt), _split(wt * np.float32(scale), terms, dt)
             acc = None
             for (ta, tb) in PRODUCTS[terms]:
                 p = F.conv2d(xs[ta], ws[tb])
                 acc = p if acc is None else acc + p
-            y = acc + bias.view(1, -1, 1, 1)
+            y = acc / scale + bias.view(1, -1, 1, 1)
         else:
             y = F.conv2d(t.to(torch.float64), wt.to(torch.float64), bias)
         y = y.to(torch.float32)                       # the accumulator is fp32

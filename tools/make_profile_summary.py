@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX> [fp32|bf16x2|bf16x3]
+"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX> [fp32|bf16x2|bf16x3|fp16x2]
 Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries:
   PREFIX_kernel_stats.csv  (rocprofv3 --kernel-trace --stats)
   PREFIX_pmc_summary.txt   (per-kernel means of every PMC counter)
@@ -9,7 +9,7 @@ FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE reports 1/2 of wide streaming
 import csv, json, os, shutil, subprocess, sys
 base, prefix = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
-T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3}[prec]
+T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3, "fp16x2": 2}[prec]
 PRODUCTS = {0: 1, 2: 3, 3: 6}[T]
 H, W, NL = 2160, 3840, 7
 PLANES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)]

@@ -48,7 +48,7 @@ def build_parser():
     ap.add_argument("--model_dir", default="models", help="path to custom model directory (don't append last / )")
     ap.add_argument("-j", "--jobs", type=int, default=4, help="number of threads launching at the same time")
     # not a reference flag: w2xc_opts.precision of the engine (fp32 = the reference's arithmetic on the fp32 MFMA)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "fp16x2", "bf16x2", "bf16"],
                     help="engine arithmetic for the CNN layers (extension; default fp32)")
     return ap
 
@@ -76,7 +76,7 @@ def main(argv=None):
     elif iterations == 0 and noise is None:
         raise SystemExit("scale_ratio %g needs no 2x step; the reference would only shrink, which is not supported without a model pass" % args.scale_ratio)
     else:
-        prec = {"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2, "bf16x3": w2xc.PRECISION_BF16X3}[args.precision]
+        prec = {"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2, "bf16x3": w2xc.PRECISION_BF16X3, "fp16x2": w2xc.PRECISION_FP16X2}[args.precision]
         opts = w2xc.make_opts(precision=prec) if prec != w2xc.PRECISION_FP32 else None
         out = w2xc.process_image_u8(bgr, noise, scale if iterations else None, iterations, opts, shrink)
     name = args.output_file

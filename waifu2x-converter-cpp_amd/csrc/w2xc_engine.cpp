@@ -67,7 +67,8 @@ struct DevLayer {
     float *w_fast = nullptr;
     float *w_direct = nullptr;
     float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
-    float *w_split[4] = {nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images per term count, packed on first use
+    float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
+    float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *bias = nullptr;
 };
 
@@ -149,12 +150,13 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
         r.struct_size = (int)sizeof(w2xc_opts);
     } else {
         // callers that pass no options (the C++ adapter behind the reference's CLI): the default precision can
-        // be switched without recompiling -- W2XC_PRECISION = fp32 | bf16x3 | bf16x2 | bf16
+        // be switched without recompiling -- W2XC_PRECISION = fp32 | bf16x3 | fp16x2 | bf16x2 | bf16
         static const int env_prec = [] {
             const char *e = getenv("W2XC_PRECISION");
             if (!e) return W2XC_PRECISION_FP32;
             if (!strcmp(e, "bf16x3")) return W2XC_PRECISION_BF16X3;
             if (!strcmp(e, "bf16x2")) return W2XC_PRECISION_BF16X2;
+            if (!strcmp(e, "fp16x2")) return W2XC_PRECISION_FP16X2;
             if (!strcmp(e, "bf16")) return W2XC_PRECISION_BF16;
             return W2XC_PRECISION_FP32;
         }();
@@ -166,8 +168,9 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
 // bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline)
 int split_terms(const w2xc_opts &o)
 {
-    return o.precision == W2XC_PRECISION_BF16X2 ? 2 : o.precision == W2XC_PRECISION_BF16X3 ? 3 : 0;
+    return (o.precision == W2XC_PRECISION_BF16X2 || o.precision == W2XC_PRECISION_FP16X2) ? 2 : o.precision == W2XC_PRECISION_BF16X3 ? 3 : 0;
 }
+int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 ? 1 : 0; }
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
@@ -283,14 +286,16 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         if (rc) return rc;
     }
     if (kind == W2XC_K_MID_SPLIT) {
-        if (d.terms < 2 || d.terms > 3) return fail(W2XC_ERR_ARG, "bad term count %d", d.terms);
-        if (!dl.w_split[d.terms]) {
+        if (d.terms < 2 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
+        const int wi = d.terms + 3 * d.fmt;
+        if (!dl.w_split[wi]) {
             std::vector<float> pk((w2xc_split_packed_bytes(d.cin, d.cout, d.terms) + 3) / 4);
-            w2xc_split_pack(d.cin, d.cout, d.terms, m->layers[l].w.data(), pk.data());
-            int rc = upload(pk, &dl.w_split[d.terms]);
+            dl.split_scale[wi] = w2xc_split_pack(d.cin, d.cout, d.terms, d.fmt, m->layers[l].w.data(), pk.data());
+            int rc = upload(pk, &dl.w_split[wi]);
             if (rc) return rc;
         }
-        d.wpk = dl.w_split[d.terms];
+        d.wpk = dl.w_split[wi];
+        d.acc_scale = 1.0f / dl.split_scale[wi];
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
     }
@@ -413,6 +418,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             int split_grp = 0;
             if (T > 0) {
                 d.terms = (kind == W2XC_K_MID_SPLIT) ? T : 0;
+                d.fmt = split_fmt(o);
                 d.in_ts = src_ts;
                 d.out_terms = out_terms_of(m, k - 1, o);
                 d.out_ts = (long long)d.out_h * d.out_w * hl.nout;
@@ -770,7 +776,7 @@ int w2xc_convert_planes_device(w2xc_model *m, int n_in_planes, const float *d_in
         return fail(W2XC_ERR_ARG, "bad plane count / plane strides");
     const w2xc_opts o = resolve_opts(opts);
     if (o.precision != W2XC_PRECISION_FP32 && split_terms(o) == 0)
-        return fail(W2XC_ERR_UNSUPPORTED, "w2xc_convert_planes_* supports W2XC_PRECISION_FP32 / BF16X2 / BF16X3");
+        return fail(W2XC_ERR_UNSUPPORTED, "w2xc_convert_planes_* supports W2XC_PRECISION_FP32 / BF16X2 / BF16X3 / FP16X2");
     int dev = o.device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     DeviceGuard guard(dev);

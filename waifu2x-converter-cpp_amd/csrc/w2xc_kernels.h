@@ -30,6 +30,8 @@ struct W2xcConvDesc {
     // out_terms = 0 stores plain fp32 NHWC.
     int terms, out_terms;
     long long in_ts, out_ts, in_gs, out_gs;
+    int fmt;             // 0 = bf16 terms, 1 = fp16 terms (W2XC_PRECISION_FP16X2)
+    float acc_scale;     // fp16: 1 / (power-of-two weight scale of this layer), applied to the accumulators
 };
 
 enum W2xcKernelKind {
@@ -62,7 +64,7 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.
 int w2xc_split_kg(int terms, int cin);
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms);
-void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst);
+float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, void *dst);   // returns the weight scale (1 for bf16)
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream);
 

@@ -10,6 +10,8 @@
 //     T = 2  (W2XC_PRECISION_BF16X2)   3 products  a0b0 + a0b1 + a1b0:            ~16-bit operands, |err| ~ 2^-17 |ab|
 //     T = 3  (W2XC_PRECISION_BF16X3)   6 products  + a1b1 + a0b2 + a2b0:          ~24-bit operands, |err| ~ 2^-24 |ab|,
 //                                                                                  i.e. the error level of an fp32 FMA chain
+//     T = 2, fp16 terms (W2XC_PRECISION_FP16X2, FMT = 1)  3 products on v_mfma_f32_32x32x16_f16: ~22-bit operands;
+//            weights pre-scaled per layer by a power of two (w2xc_split_pack), activations clamped to +-65504
 //
 // Activations between the layers are T bf16 "term planes" (`ts` elements apart), each channel-group blocked:
 // element (c, y, x) at (c / G)*gs + y*rs + x*G + c % G with G = 16*KG = the consumer's K-slice, so the halo tile
@@ -28,13 +30,14 @@
 #include "w2xc_device.h"
 
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include <atomic>
 #include <type_traits>
 
 #ifndef W2XC_SPLIT_T
-#error "compile with -DW2XC_SPLIT_T=2 or -DW2XC_SPLIT_T=3 (one object per term count, see the Makefile)"
+#error "compile with -DW2XC_SPLIT_T=2, 3 or 4 (= fp16 x 2): one object per variant, see the Makefile"
 #endif
 #ifndef W2XC_SPLIT_LATE
 #define W2XC_SPLIT_LATE 4   // MFMAs kept after the last fragment read of a step
@@ -51,23 +54,46 @@ static __device__ __forceinline__ unsigned pk_bf16(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// v_cvt_pk_f16_f32 (round to nearest even)
+static __device__ __forceinline__ unsigned pk_f16(float a, float b)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_t));
+}
+
 // Store 4 consecutive channels of one pixel as OT term planes (OT >= 1) or as fp32 (OT == 0).
-template <int OT>
+// FMT = 0: bf16 terms (same exponent range as fp32).  FMT = 1: fp16 terms -- values are clamped to the fp16
+// range (+-65504) first; residuals below 2^-14 are held to 2^-25 absolute by fp16's subnormals.
+template <int OT, int FMT>
 static __device__ __forceinline__ void store_terms(float *out, long long elem_off, long long out_ts, float v0, float v1, float v2, float v3)
 {
     if (OT == 0) {
         *reinterpret_cast<f32x4 *>(out + elem_off) = (f32x4){v0, v1, v2, v3};
     } else {
         bf16_t *o16 = reinterpret_cast<bf16_t *>(out) + elem_off;
+        if (FMT == 1) {
+            v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
+            v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
+            v2 = __builtin_amdgcn_fmed3f(v2, -65504.0f, 65504.0f);
+            v3 = __builtin_amdgcn_fmed3f(v3, -65504.0f, 65504.0f);
+        }
 #pragma unroll
         for (int t = 0; t < OT; t++) {
-            const unsigned p01 = pk_bf16(v0, v1), p23 = pk_bf16(v2, v3);
+            const unsigned p01 = FMT ? pk_f16(v0, v1) : pk_bf16(v0, v1), p23 = FMT ? pk_f16(v2, v3) : pk_bf16(v2, v3);
             *reinterpret_cast<u32x2 *>(o16 + (long long)t * out_ts) = (u32x2){p01, p23};
-            if (t + 1 < OT) {   // exact residuals: |v - bf16(v)| fits fp32
-                v0 -= __uint_as_float(p01 << 16);
-                v1 -= __uint_as_float(p01 & 0xFFFF0000u);
-                v2 -= __uint_as_float(p23 << 16);
-                v3 -= __uint_as_float(p23 & 0xFFFF0000u);
+            if (t + 1 < OT) {   // exact residuals: |v - round(v)| fits fp32
+                if (FMT) {
+                    const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
+                    const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
+                    v0 -= b01[0]; v1 -= b01[1]; v2 -= b23[0]; v3 -= b23[1];
+                } else {
+                    v0 -= __uint_as_float(p01 << 16);
+                    v1 -= __uint_as_float(p01 & 0xFFFF0000u);
+                    v2 -= __uint_as_float(p23 << 16);
+                    v3 -= __uint_as_float(p23 & 0xFFFF0000u);
+                }
             }
         }
     }
@@ -136,7 +162,7 @@ template <int APW, int LASTA> static __device__ constexpr int ka_window(int tap,
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW, NPIXP = 352;
@@ -330,9 +356,14 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 static_for<0, M>([&](auto MI) {
                     constexpr int m = decltype(MI)::value;            // MFMA index in the step
                     constexpr int pi = m / (MB * NB), mb = (m / NB) % MB, nb = m % NB;
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, w_cur[Prod<T>::b(pi)][nb]),
-                        __builtin_bit_cast(bf16x8, x_cur[Prod<T>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
+                    if constexpr (FMT == 1)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(h16x8, w_cur[Prod<T>::b(pi)][nb]),
+                            __builtin_bit_cast(h16x8, x_cur[Prod<T>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
+                    else
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, w_cur[Prod<T>::b(pi)][nb]),
+                            __builtin_bit_cast(bf16x8, x_cur[Prod<T>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
                     constexpr int f0 = m < D ? (m * F + D - 1) / D : F;
                     constexpr int f1 = m < D ? (((m + 1) * F + D - 1) / D < F ? ((m + 1) * F + D - 1) / D : F) : F;
                     static_for<f0, f1>([&](auto FI) {
@@ -400,11 +431,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const float s = acc[mb][nb][4 * i + e] + bv[nb][4 * i + e];
+                                // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
+                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bv[nb][4 * i + e];
                                 v[e] = fmaxf(s, 0.1f * s);
                                 acc[mb][nb][4 * i + e] = 0.0f;
                             }
-                            store_terms<OT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
+                            store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
                         }
                 epi_stores = true;
             } else {
@@ -419,11 +451,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const float s = acc[mb][nb][4 * i + e] + bv[nb][4 * i + e];
+                                // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
+                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bv[nb][4 * i + e];
                                 v[e] = fmaxf(s, 0.1f * s);
                                 acc[mb][nb][4 * i + e] = 0.0f;
                             }
-                            if (in) store_terms<OT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
+                            if (in) store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
                         }
                 }
             }
@@ -442,7 +475,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 // clamp-to-edge pad and the optional nearest-neighbour 2x folded into the LDS fill) with the operands
 // swapped, so that a lane holds 4 consecutive channels of one pixel and stores OT term planes directly.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int NBT, int OT>
+template <int CIN, int NBT, int OT, int FMT>
 __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2;
@@ -504,7 +537,7 @@ __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int t
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e] + d.bias[nb * 32 + 8 * q + 4 * kk + e]);
                     const int c = nb * 32 + 8 * q + 4 * kk;      // blocked term planes (see conv3x3_split)
-                    store_terms<OT>(d.out, (long long)(c / OSLC) * d.out_gs + (long long)y * d.out_rs + (long long)x * OSLC + c % OSLC, d.out_ts,
+                    store_terms<OT, FMT>(d.out, (long long)(c / OSLC) * d.out_gs + (long long)y * d.out_rs + (long long)x * OSLC + c % OSLC, d.out_ts,
                                     v[0], v[1], v[2], v[3]);
                 }
             }
@@ -520,8 +553,11 @@ int w2xc_split_kg(int terms, int cin) { (void)cin; return terms == 3 ? 1 : 2; }
 
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
 
-// wpk[tap][slice][term][g][nb][lane][8] (bf16) = term `term` of W[32*nb + (lane&31)][slice*16*KG + 16*g + 8*(lane>>5) + e][tap]
-void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst)
+// wpk[tap][slice][term][g][nb][lane][8] (16-bit) = term `term` of S * W[32*nb + (lane&31)][slice*16*KG + 16*g + 8*(lane>>5) + e][tap]
+// fmt 0: bf16 terms, S = 1.  fmt 1: fp16 terms, S = the power of two that puts max|W| into [2^14, 2^15): the low
+// term of every weight down to 2^-17 max|W| is then a NORMAL fp16 number (22 significant bits in two terms).
+// Returns S; the consumer multiplies its accumulators by 1/S (exact).
+float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, void *dst)
 {
     auto bf = [](float f) -> unsigned short {
         unsigned u;
@@ -535,6 +571,16 @@ void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst)
         memcpy(&f, &u, 4);
         return f;
     };
+    float scale = 1.0f;
+    if (fmt == 1) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < (size_t)9 * cin * cout; i++) mx = fabsf(w[i]) > mx ? fabsf(w[i]) : mx;
+        if (mx > 0.0f && mx < INFINITY) {
+            int e = 0;
+            frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+            scale = ldexpf(1.0f, 15 - e);   // mx * scale in [2^14, 2^15)
+        }
+    }
     const int kg = w2xc_split_kg(terms, cin), nsl = cin / (16 * kg), nbt = cout / 32;
     unsigned short *d16 = static_cast<unsigned short *>(dst);
     for (int tap = 0; tap < 9; tap++)
@@ -544,18 +590,27 @@ void w2xc_split_pack(int cin, int cout, int terms, const float *w, void *dst)
                     for (int lane = 0; lane < 64; lane++)
                         for (int e = 0; e < 8; e++) {
                             const int o = nb * 32 + (lane & 31), c = sl * 16 * kg + 16 * g + 8 * (lane >> 5) + e;
-                            float r = w[((size_t)o * cin + c) * 9 + tap];
+                            float r = w[((size_t)o * cin + c) * 9 + tap] * scale;   // exact (power of two)
                             for (int t = 0; t < terms; t++) {
-                                const unsigned short h = bf(r);
+                                unsigned short h;
+                                float back;
+                                if (fmt == 1) {
+                                    const _Float16 hf = (_Float16)r;                 // round to nearest even
+                                    memcpy(&h, &hf, 2);
+                                    back = (float)hf;
+                                } else {
+                                    h = bf(r);
+                                    back = bf2f(h);
+                                }
                                 d16[((((((size_t)tap * nsl + sl) * terms + t) * kg + g) * nbt + nb) * 64 + lane) * 8 + e] = h;
-                                r -= bf2f(h);
+                                r -= back;
                             }
                         }
+    return scale;
 }
-
 #endif
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
 static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
@@ -564,7 +619,7 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     constexpr int A_PIECES = T * 352 * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
     constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING>;
+    auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -582,7 +637,7 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
 
 // tile shapes per (cin, cout): 4 waves, one per SIMD (8 waves, two per SIMD, measured within 2 %: the big
 // layers run against the power limit -- the shader clock sits at ~1.8 GHz under the dense bf16 MFMA stream)
-template <int T, int OT>
+template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr int KG = T == 3 ? 1 : 2;     // k-groups (16 channels) per slice = per channel group of the layout
@@ -590,28 +645,28 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                CIN  COUT  MB NB WM WN
-    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
-    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
-    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
-    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
-    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
-    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
-    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KG, RG>(d, stream);
-    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG>(d, stream);
+    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
+    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
+    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
 #endif
-    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KG, RG>(d, stream);
+    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 // One object file per term count (Makefile: -DW2XC_SPLIT_T=2 / 3) so the two sets of instantiations compile
 // in parallel; the T = 3 object also carries the shared host code below.
-template <int OT>
+template <int OT, int FMT>
 static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
-#define W2XC_FS(CIN, NBT) hipLaunchKernelGGL((conv3x3_first_split<CIN, NBT, OT>), dim3(ntiles), dim3(256), 0, stream, d, tiles_x, ntiles); break
+#define W2XC_FS(CIN, NBT) hipLaunchKernelGGL((conv3x3_first_split<CIN, NBT, OT, FMT>), dim3(ntiles), dim3(256), 0, stream, d, tiles_x, ntiles); break
     switch (d.cin * 1000 + d.cout) {
     case 1032:  W2XC_FS(1, 1);
     case 1064:  W2XC_FS(1, 2);
@@ -628,25 +683,34 @@ static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream
 #if W2XC_SPLIT_T == 2
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
 {
-    return d.out_terms == 2 ? launch_split_t<2, 2>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0>(d, stream) : hipErrorInvalidValue;
+    return d.out_terms == 2 ? launch_split_t<2, 2, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 0>(d, stream) : hipErrorInvalidValue;
 }
-hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2>(d, stream); }
+hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 0>(d, stream); }
+#elif W2XC_SPLIT_T == 4   // fp16 x 2
+hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream)
+{
+    return d.out_terms == 2 ? launch_split_t<2, 2, 1>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 1>(d, stream) : hipErrorInvalidValue;
+}
+hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 1>(d, stream); }
 #else
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream);
 
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
-    if (d.terms == 2) return w2xc_launch_split_mid_2(d, stream);
-    if (d.terms != 3) return hipErrorInvalidValue;
-    return d.out_terms == 3 ? launch_split_t<3, 3>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0>(d, stream) : hipErrorInvalidValue;
+    if (d.terms == 2) return d.fmt == 1 ? w2xc_launch_split_mid_h(d, stream) : w2xc_launch_split_mid_2(d, stream);
+    if (d.terms != 3 || d.fmt != 0) return hipErrorInvalidValue;
+    return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream) : hipErrorInvalidValue;
 }
 
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    return d.out_terms == 2 ? w2xc_launch_split_first_2(d, stream) : d.out_terms == 3 ? launch_first_split_t<3>(d, stream) : hipErrorInvalidValue;
+    if (d.out_terms == 2) return d.fmt == 1 ? w2xc_launch_split_first_h(d, stream) : w2xc_launch_split_first_2(d, stream);
+    return (d.out_terms == 3 && d.fmt == 0) ? launch_first_split_t<3, 0>(d, stream) : hipErrorInvalidValue;
 }
 #endif
