@@ -423,7 +423,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 d.out_terms = out_terms_of(m, k - 1, o);
                 d.out_ts = (long long)d.out_h * d.out_w * hl.nout;
                 d.in_gs = src_gs;
-                split_grp = d.out_terms == 3 ? 16 : 32;                 // channel-group size of the blocked term planes
+                split_grp = 16;                                         // channel-group size of the blocked term planes
                 d.out_gs = (long long)d.out_h * d.out_w * split_grp;
             }
             const bool direct_out = (k == n && last_direct);

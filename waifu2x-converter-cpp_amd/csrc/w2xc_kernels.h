@@ -26,7 +26,7 @@ struct W2xcConvDesc {
     // first-layer kernels (conv3x3_first, conv3x3_direct) honour it.
     int in_shift;
     // split-bf16 kernels (w2xc_split.hip): an activation tensor is `terms` bf16 term planes, each channel-group
-    // blocked: element (t, c, y, x) at t*ts + (c / G)*gs + y*rs + x*G + c % G  (ELEMENTS; G = 16 for 3 terms, else 32).
+    // blocked: element (t, c, y, x) at t*ts + (c / G)*gs + y*rs + x*G + c % G  (ELEMENTS; G = 16).
     // out_terms = 0 stores plain fp32 NHWC.
     int terms, out_terms;
     long long in_ts, out_ts, in_gs, out_gs;

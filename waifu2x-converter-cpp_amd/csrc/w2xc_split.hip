@@ -106,10 +106,10 @@ template <> struct Prod<1> {
     static __device__ constexpr int a(int) { return 0; }
     static __device__ constexpr int b(int) { return 0; }
 };
-template <> struct Prod<2> {
+template <> struct Prod<2> {   // (x1,w0), (x0,w0), (x0,w1): each fragment group is live in consecutive products (rolling registers)
     static constexpr int N = 3;
     static __device__ constexpr int a(int i) { return i == 0 ? 1 : 0; }
-    static __device__ constexpr int b(int i) { return i == 1 ? 1 : 0; }
+    static __device__ constexpr int b(int i) { return i == 2 ? 1 : 0; }
 };
 template <> struct Prod<3> {
     static constexpr int N = 6;
@@ -165,14 +165,15 @@ template <int APW, int LASTA> static __device__ constexpr int ka_window(int tap,
 template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcConvDesc d, int tiles_x, int ntiles)
 {
-    constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW, NPIXP = 352;
+    constexpr int ROWS = MB * WM;                     // 8 or 16 output rows per tile
+    constexpr int HW = 34, HH = ROWS + 2, NPIX = HH * HW, NPIXP = (NPIX + 31) / 32 * 32;   // 340 -> 352, 612 -> 640
     constexpr int NCH = 2 * KG;                       // 16-byte chunks per pixel per term in one slice
     constexpr int PXB = 32 * KG;                      // bytes per pixel per term
     constexpr int SWS = NCH == 2 ? 3 : NCH == 4 ? 2 : 1;   // swizzle: chunk q of pixel p sits at q ^ ((p >> SWS) & (NCH-1))
     constexpr int SLC = 16 * KG;                      // channels per slice = channel-group size of the blocked layout
     constexpr int NSL = CIN / SLC, NBT = COUT / 32;
     constexpr int NW = WM * WN;
-    constexpr unsigned A_TERM = NPIXP * PXB;          // bytes of one term of the halo tile (352 = 340 padded to 1 KiB pieces)
+    constexpr unsigned A_TERM = NPIXP * PXB;          // bytes of one term of the halo tile (pixels padded to whole 1 KiB pieces)
     constexpr int A_SLOTS = T * NPIXP * NCH;          // 16-byte slots
     constexpr int A_PIECES = A_SLOTS / 64;            // 1 KiB pieces = T * 11 * KG
     constexpr int APW = (A_PIECES + NW - 1) / NW;     // pieces per wave per slice
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr int LASTA = 10 - RING < 5 ? 10 - RING : 5;   // A pieces of the next slice are issued on taps 0..LASTA: landed by the end of tap 7,
                                                            // because tap 8's last step already reads the next slice's first fragments
     constexpr int NST = MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
-    static_assert((NW == 4 || NW == 8) && MB * WM == ROWS && NB * WN == NBT, "tile shape");
+    static_assert((NW == 4 || NW == 8) && (ROWS == 8 || ROWS == 16) && NB * WN == NBT, "tile shape");
     static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
     static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 2, "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -208,12 +209,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     int tile = chunk_begin + (blockIdx.x >> 3);
     if (tile >= chunk_end) return;
 
-    // bias of the 16 channels this lane holds per plane block: channel = (r&3) + 8*(r>>2) + 4*kk
-    float bv[NB][16];
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) bv[nb][r] = d.bias[(nb0 + nb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk];
+    // bias[COUT] sits behind the weight ring; lane (li, kk) reads the 4 channels of a register quad as one b128
+    constexpr unsigned BIAS_BASE = B_BASE + RING * B_BYTES;
+    for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c];   // visible after the prologue barrier
 
     // ---- per-lane DMA source offsets of the A halo tile, in 16-byte units (8 bf16) ----
     const u32x4 *in4 = reinterpret_cast<const u32x4 *>(d.in);
@@ -312,11 +310,11 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     bool epi_stores = false;   // an interior-tile epilogue (NST stores) directly precedes the current slice
     u32x4 x_cur[T][MB], w_cur[T][NB];
 #pragma unroll
-    for (int t = 0; t < T; t++) {
+    for (int t = 0; t < T; t++) {   // (the two-term schedule reads x0 / w1 inside the step)
 #pragma unroll
-        for (int mb = 0; mb < MB; mb++) x_cur[t][mb] = *x_addr(0, t, mb, 0, 0);
+        for (int mb = 0; mb < MB; mb++) x_cur[t][mb] = *x_addr(0, (T == 2) ? 1 : t, mb, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) w_cur[t][nb] = *w_addr(0, t, 0, nb);
+        for (int nb = 0; nb < NB; nb++) w_cur[t][nb] = *w_addr(0, (T == 2) ? 0 : t, 0, nb);
     }
 
     for (;;) {
@@ -336,6 +334,52 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             const unsigned buf = gs, bufL = gs + LEAD >= RING ? gs + LEAD - RING : gs + LEAD, buf1 = gs + 1 >= RING ? 0 : gs + 1;
             // A pieces of the next slice: ka(t) = ceil-spread of APW over taps 0..LASTA, at most 2 per tap
             constexpr int ja0 = ka_before<APW, LASTA>(tap);
+            if constexpr (T == 2) {
+                // Two terms, one k-group per stage: "rolling" fragment registers.  Products run (x1,w0), (x0,w0), (x0,w1);
+                // each fragment group is reloaded right after its last use and first needed >= MB*NB MFMAs later:
+                //   product 0 window: x0, w1 of THIS step      (free since the previous step's last product)
+                //   product 1 window: the step's DMAs, then x1 of the NEXT step
+                //   product 2 window: w0 of the NEXT step
+                // so one set of fragment registers (12 for the 4x2 blocking) serves instead of two.
+                static_assert(KG == 1, "rolling schedule: one k-group per stage");
+                constexpr int Q = MB * NB, M = 3 * Q;
+                constexpr int n_a = ka<APW, LASTA>(tap), n_b = BPW;
+                constexpr int tap_n = (tap + 1) % 9;
+                const unsigned abuf_n = (tap == 8) ? (abuf ^ 1u) : abuf;
+                static_for<0, M>([&](auto MI) {
+                    constexpr int m = decltype(MI)::value;
+                    constexpr int pi = m / Q, j = m % Q, mb = j / NB, nb = j % NB;
+                    if constexpr (FMT == 1)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(h16x8, w_cur[Prod<2>::b(pi)][nb]),
+                            __builtin_bit_cast(h16x8, x_cur[Prod<2>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
+                    else
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, w_cur[Prod<2>::b(pi)][nb]),
+                            __builtin_bit_cast(bf16x8, x_cur[Prod<2>::a(pi)][mb]), acc[mb][nb], 0, 0, 0);
+                    // fillers of this window that sit behind MFMA j: windows 0 and 2 front-loaded, window 1 spread
+                    constexpr int nwin = pi == 0 ? MB + NB : pi == 1 ? n_a + n_b + MB : NB;
+                    static_for<0, nwin>([&](auto FI) {
+                        constexpr int f = decltype(FI)::value;
+                        constexpr int slot = pi == 1 ? (f * Q) / nwin : (f < Q ? f : Q - 1);
+                        if constexpr (slot == j) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (pi == 0) {
+                                if constexpr (f < MB) x_cur[0][f] = *x_addr(abuf, 0, f, tap, 0);
+                                else w_cur[1][f - MB] = *w_addr(buf, 1, 0, f - MB);
+                            } else if constexpr (pi == 1) {
+                                if constexpr (f < n_a) dma_a(a_add, abuf ^ 1u, ja0 + f);
+                                else if constexpr (f < n_a + n_b) dma_b(slL, tapL, bufL, f - n_a);
+                                else x_cur[1][f - n_a - n_b] = *x_addr(abuf_n, 1, f - n_a - n_b, tap_n, 0);
+                            } else {
+                                w_cur[0][f] = *w_addr(buf1, 0, 0, f);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            } else
             static_for<0, KG>([&](auto G) {
                 constexpr int g = decltype(G)::value;
                 // One step = M MFMAs on k-group g; the other instructions are pinned into MFMA shadows:
@@ -429,10 +473,11 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             float v[4];
+                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
                                 // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
-                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bv[nb][4 * i + e];
+                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bq[e];
                                 v[e] = fmaxf(s, 0.1f * s);
                                 acc[mb][nb][4 * i + e] = 0.0f;
                             }
@@ -449,10 +494,11 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             float v[4];
+                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
                                 // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
-                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bv[nb][4 * i + e];
+                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bq[e];
                                 v[e] = fmaxf(s, 0.1f * s);
                                 acc[mb][nb][4 * i + e] = 0.0f;
                             }
@@ -479,7 +525,7 @@ template <int CIN, int NBT, int OT, int FMT>
 __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2;
-    constexpr int OSLC = OT == 3 ? 16 : 32;           // channel-group size of the consumer (16 * its KG)
+    constexpr int OSLC = 16;                          // channel-group size of the consumer (16 * its KG)
     constexpr int K = 9 * CIN, S = (K + 1) / 2;
     constexpr int COUT = 32 * NBT;
     __shared__ float lds[CIN * HH * HW];
@@ -549,7 +595,7 @@ __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int t
 // host side
 // ================================================================================================
 #if W2XC_SPLIT_T == 3   // shared host code lives in one object
-int w2xc_split_kg(int terms, int cin) { (void)cin; return terms == 3 ? 1 : 2; }
+int w2xc_split_kg(int terms, int cin) { (void)terms; (void)cin; return 1; }   // 16-channel slices = channel groups of the layout
 
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
 
@@ -613,11 +659,12 @@ float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, voi
 template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
 static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
 {
-    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    constexpr int ROWS = MB * WM, NPIXP = ((ROWS + 2) * 34 + 31) / 32 * 32;
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + ROWS - 1) / ROWS;
     const int ntiles = tiles_x * tiles_y;
     constexpr int NW = WM * WN;
-    constexpr int A_PIECES = T * 352 * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
-    constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024);
+    constexpr int A_PIECES = T * NPIXP * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
+    constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
@@ -635,32 +682,32 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// tile shapes per (cin, cout): 4 waves, one per SIMD (8 waves, two per SIMD, measured within 2 %: the big
-// layers run against the power limit -- the shader clock sits at ~1.8 GHz under the dense bf16 MFMA stream)
+// Tile shapes per (cin, cout).  Three terms: 8 rows x 32 px, 4 waves (one per SIMD); the 16-row tile does not fit
+// the LDS with three term planes.  Two terms: 16 rows x 32 px, 8 waves (two per SIMD) for the 64/128-plane outputs --
+// every weight stage streamed from L2 serves twice the pixels and the halo overhead drops from 1.33 to 1.20; these
+// layers run against the power limit (shader clock ~1.65 GHz), so bytes moved per MFMA are what is left to save.
 template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
-    constexpr int KG = T == 3 ? 1 : 2;     // k-groups (16 channels) per slice = per channel group of the layout
-    constexpr int RG = T == 3 ? 6 : 4;
+    constexpr int KG = 1, RG = 6;
+    constexpr bool BIG = (T == 2);
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
-    //                                CIN  COUT  MB NB WM WN
+    //                                     CIN  COUT  MB NB WM WN
     case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 32064:  return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 32128:  return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
     case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 64064:  return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 64128:  return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
     case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 128064: return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream);
+    case 32064: { if constexpr (BIG) return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 64064: { if constexpr (BIG) return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 128064: { if constexpr (BIG) return launch_split<128, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 32128: { if constexpr (BIG) return launch_split<32, 128, 4, 2, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream); }
+    case 64128: { if constexpr (BIG) return launch_split<64, 128, 4, 2, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream); }
 #endif
-    case 128128: return launch_split<128, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream);
+    case 128128: { if constexpr (BIG) return launch_split<128, 128, 4, 2, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<128, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream); }
     default: return hipErrorInvalidValue;
     }
 }
 
-// One object file per term count (Makefile: -DW2XC_SPLIT_T=2 / 3) so the two sets of instantiations compile
-// in parallel; the T = 3 object also carries the shared host code below.
 template <int OT, int FMT>
 static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
