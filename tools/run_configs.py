@@ -77,6 +77,14 @@ sub = orc.Oracle(slayers).convert(up, block_splitting=False, njob=8)
 out["cfg3_scale2x_8192x8192_1gpu"] = {"gpu_s": round(t, 4), "input_Mpix_s": round(8192 * 8192 / t / 1e6, 2),
                                       "entry": "w2xc_convert_plane_nn2x_device (nearest 2x fused into layer 1), workspace-banded",
                                       "patch_max_rel_err_vs_oracle": rel_err(got, sub[20:84, 20:84])}
+# the same frame at the opt-in precisions (same entry point, same patch check)
+for pname, prec in (("fp16x2", w2xc.PRECISION_FP16X2), ("bf16x3", w2xc.PRECISION_BF16X3)):
+    po = w2xc.make_opts(device=0, precision=prec)
+    t = gpu_time(lambda: mscale.convert_nn2x_device(d_small.data_ptr(), 8192 * 4, 8192, 8192, d_big.data_ptr(), W * 4,
+                                                    stream=st.cuda_stream, opts=po), 2)
+    got = d_big[5000:5064, 9000:9064].cpu().numpy()
+    out["cfg3_scale2x_8192x8192_1gpu"][pname] = {"gpu_s": round(t, 4), "input_Mpix_s": round(8192 * 8192 / t / 1e6, 2),
+                                                "patch_max_rel_err_vs_oracle": rel_err(got, sub[20:84, 20:84])}
 print("cfg3", out["cfg3_scale2x_8192x8192_1gpu"], flush=True)
 del d_big, d_small
 
@@ -88,7 +96,7 @@ d_y = torch.from_numpy(y).cuda()
 d_n = torch.empty_like(d_y)
 d_s = torch.empty((8192, 8192), dtype=torch.float32, device="cuda")
 res = {}
-for prec, name in ((w2xc.PRECISION_BF16, "bf16"), (w2xc.PRECISION_FP32, "fp32")):
+for prec, name in ((w2xc.PRECISION_BF16, "bf16"), (w2xc.PRECISION_FP16X2, "fp16x2"), (w2xc.PRECISION_FP32, "fp32")):
     po = w2xc.make_opts(device=0, precision=prec)
 
     def cascade():
