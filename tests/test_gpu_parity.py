@@ -198,18 +198,19 @@ def test_device_pointer_entry_point(gpu, scale_layers):
     assert launches == [1] * 7 and all(t > 0 for t in ms_t)
 
 
+@pytest.mark.parametrize("precision", [0, 3, 4])   # fp32, BF16X3, FP16X2
 @pytest.mark.parametrize("parts", [2, 3])
-def test_row_band_entry_point(gpu, scale_layers, parts):
+def test_row_band_entry_point(gpu, scale_layers, parts, precision):
     """w2xc_convert_rows_device: shards of one plane are independent and stitch bit-exactly
-    (the multi-GPU decomposition, exercised here on one device)."""
+    (the multi-GPU decomposition, exercised here on one device) -- in every precision."""
     torch = pytest.importorskip("torch")
     ms = gpu._ModelSet.from_layers(scale_layers)
     h, w = 150, 90
     x = rand_plane(h, w, 13)
-    whole = ms.convert(x)
+    whole = ms.convert(x, opts=gpu.make_opts(precision=precision))
     out = torch.zeros((h, w), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream()
-    o = gpu.make_opts(device=0)
+    o = gpu.make_opts(device=0, precision=precision)
     for p in range(parts):
         ra, rb = gpu.shard_rows(h, parts, p)
         y0, y1 = gpu.shard_view(h, ra, rb, ms.n_layers)
@@ -282,7 +283,8 @@ def test_full_size_patches_and_band_invariance(gpu, scale_layers):
     assert np.array_equal(got, banded)
 
 
-def test_large_plane_beyond_4gib_buffers(gpu, scale_layers):
+@pytest.mark.parametrize("precision", [0, 3, 4])   # fp32, BF16X3 (20.8 GB term buffers), FP16X2
+def test_large_plane_beyond_4gib_buffers(gpu, scale_layers, precision):
     """maximum sizes: a 3000 x 9000 plane in ONE band makes the 128-plane activation buffers 13.9 GB each,
     so every kernel addresses well past 2^32 bytes; patches at the far end (highest addresses), at a band
     seam of a second, banded run and at the borders are checked against the oracle."""
@@ -290,7 +292,7 @@ def test_large_plane_beyond_4gib_buffers(gpu, scale_layers):
     H, W = 3000, 9000
     rng = np.random.default_rng(77)
     plane = rng.random((H, W), dtype=np.float32)
-    got = ms.convert(plane, opts=gpu.make_opts(workspace_mb=40000))
+    got = ms.convert(plane, opts=gpu.make_opts(workspace_mb=60000, precision=precision))
     assert np.isfinite(got).all()
     o = orc.Oracle(scale_layers)
     for (y, x) in [(H - 40, W - 40), (H - 40, 0), (0, W - 40), (1499, 4500), (2990, 8000), (2000, 8960)]:
@@ -299,7 +301,7 @@ def test_large_plane_beyond_4gib_buffers(gpu, scale_layers):
         y0, y1, x0, x1 = max(0, y - 7), min(H, y + ph + 7), max(0, x - 7), min(W, x + pw + 7)
         sub = o.convert(np.ascontiguousarray(plane[y0:y1, x0:x1]), block_splitting=False, njob=8)
         assert_close(got[y:y + ph, x:x + pw], sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw], "patch (%d,%d)" % (y, x))
-    banded = ms.convert(plane, opts=gpu.make_opts(workspace_mb=6000))
+    banded = ms.convert(plane, opts=gpu.make_opts(workspace_mb=6000, precision=precision))
     assert np.array_equal(got, banded)
 
 
