@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr int NST = MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
     static_assert((NW == 4 || NW == 8) && (ROWS == 8 || ROWS == 16) && NB * WN == NBT, "tile shape");
     static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
-    static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 2, "pipeline shape");
+    static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
@@ -682,10 +682,11 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// Tile shapes per (cin, cout).  Three terms: 8 rows x 32 px, 4 waves (one per SIMD); the 16-row tile does not fit
-// the LDS with three term planes.  Two terms: 16 rows x 32 px, 8 waves (two per SIMD) for the 64/128-plane outputs --
-// every weight stage streamed from L2 serves twice the pixels and the halo overhead drops from 1.33 to 1.20; these
-// layers run against the power limit (shader clock ~1.65 GHz), so bytes moved per MFMA are what is left to save.
+// Tile shapes per (cin, cout).  16 rows x 32 px wherever the LDS allows: every weight stage streamed from L2 serves
+// twice the pixels and the halo overhead drops from 1.33 to 1.20 -- these kernels run against the power limit (shader
+// clock 1.5-1.8 GHz), so bytes moved per MFMA are what is left to save.  Two terms: 8 waves (two per SIMD, rolling
+// fragment registers) for the 64/128-plane outputs, 4 waves for 32.  Three terms: 4 waves; the 128-plane outputs stay
+// on 8-row tiles (A[2] of a 16-row tile + the weight ring would need 192 KiB).
 template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -694,12 +695,12 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                     CIN  COUT  MB NB WM WN
-    case 32032:  return launch_split<32, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 64032:  return launch_split<64, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 128032: return launch_split<128, 32, 2, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream);
-    case 32064: { if constexpr (BIG) return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
-    case 64064: { if constexpr (BIG) return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
-    case 128064: { if constexpr (BIG) return launch_split<128, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<128, 64, 2, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 32032: { if constexpr (BIG) return launch_split<32, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 64032: { if constexpr (BIG) return launch_split<64, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 128032: { if constexpr (BIG) return launch_split<128, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); else return launch_split<128, 32, 4, 1, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 32064: { if constexpr (BIG) return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 64, 4, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 64064: { if constexpr (BIG) return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 64, 4, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
+    case 128064: { if constexpr (BIG) return launch_split<128, 64, 4, 1, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<128, 64, 4, 2, 4, 1, T, OT, KG, RG, FMT>(d, stream); }
     case 32128: { if constexpr (BIG) return launch_split<32, 128, 4, 2, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<32, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream); }
     case 64128: { if constexpr (BIG) return launch_split<64, 128, 4, 2, 4, 2, T, OT, KG, RG, FMT>(d, stream); else return launch_split<64, 128, 4, 2, 2, 2, T, OT, KG, RG, FMT>(d, stream); }
 #endif
