@@ -692,3 +692,36 @@ def test_cli_shell_precision_flag(gpu, models_dir, tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(np.asarray(Image.open(o)).astype(np.int16))
     assert outs[0].shape == (48, 56, 3) and np.abs(outs[0] - outs[1]).max() <= 1
+
+
+def test_fused_last_layer_vs_unfused(gpu, tmp_path):
+    """two-term modes compute the one-plane last layer inside the epilogue of the layer before it (conv3x3_split
+    out_terms = 9 + conv3x3_last_gather).  W2XC_SPLIT_FUSE_LAST=0 restores the separate fp32 conv3x3_last: the two
+    must agree to the fp32-order level on odd sizes, borders, banding and the nearest-2x entry point."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "w = g.load_package(); outs = []; flags = []\n"
+        "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 1], 7), ([1, 64, 32, 1], 8)):\n"
+        "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
+        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2):\n"
+        "        for (h, wd) in ((37, 61), (8, 32), (130, 70)):\n"
+        "            x = np.random.default_rng(h).random((h, wd), dtype=np.float32)\n"
+        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec)).ravel())\n"
+        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec, band_rows=11)).ravel())\n"
+        "            outs.append(ms.convert_nn2x(x, w.make_opts(precision=prec)).ravel())\n"
+        "    flags.append(float(ms.kernel_name(len(planes) - 2, w.make_opts(precision=w.PRECISION_FP16X2)) == 'conv3x3_last_gather'))\n"
+        "np.save(sys.argv[1], np.concatenate(outs + [np.array(flags)]))\n" % ROOT)
+    res = []
+    for fuse in ("1", "0"):
+        f = str(tmp_path / ("o%s.npy" % fuse))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_SPLIT_FUSE_LAST=fuse), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        res.append(np.load(f))
+    a, b = res
+    assert a.shape == b.shape
+    assert (a[-3:] == 1.0).all() and (b[-3:] == 0.0).all()          # the fused path really ran (and really did not)
+    scale = np.abs(b[:-3]).max()
+    assert np.abs(a[:-3] - b[:-3]).max() <= 1e-4 * scale            # BF16X2 bound; FP16X2 is ~1e-6

@@ -30,7 +30,9 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
     else:
         sub = ("conv3x3_first_split<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_split<%d, %d," % (cin, cout))
-    names = [n for n in stats if sub in n and n.startswith("void conv3x3")]
+        if k == NL and T == 2 and any(n.startswith("conv3x3_last_gather") for n in stats):
+            sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
+    names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
     if not names:
         continue
     name = names[0]
@@ -42,11 +44,19 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     in_bpe = 4 if (T == 0 or k == 1 or k == NL) else 2 * T
     out_bpe = 4 if (T == 0 or k >= NL - 1) else 2 * T
     alg = (cin * in_bpe + cout * out_bpe) * px
+    if sub == "conv3x3_last_gather":
+        alg = (2 * 9 * 4 + 4) * px                      # two halves of 9 tap planes in, one plane out
+    if T == 2 and k == NL - 1 and any(n.startswith("conv3x3_last_gather") for n in stats):
+        alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px,
          "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,
          "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
          "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}
+    if sub == "conv3x3_last_gather":   # the last layer's MFMA work runs inside layer NL-1's kernel; this kernel only adds 18 floats per pixel
+        e["algorithmic_flops"] = 18 * px
+        e["tflops"] = 18 * px / avg_ns / 1e3
+        e["note"] = "last layer fused into the previous kernel's epilogue; this is the tap/half gather"
     grbm = mean_counter(pmcs[3], sub, "GRBM_GUI_ACTIVE"); busy = mean_counter(pmcs[2], sub, "SQ_VALU_MFMA_BUSY_CYCLES")
     if grbm and busy:
         e.update({"shader_clock_GHz": grbm / 8 / avg_ns, "mfma_pipe_utilisation": busy / (1024 * grbm / 8),

@@ -69,6 +69,8 @@ struct DevLayer {
     float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
+    float *w_last_fused[2] = {nullptr, nullptr};   // w2xc_split_pack_last image per format (bf16 / fp16), packed on first use
+    float last_fused_scale[2] = {1, 1};
     float *bias = nullptr;
 };
 
@@ -99,6 +101,8 @@ struct DevCtx {
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_bf16) hipFree(l.w_bf16);
             for (float *p : l.w_split)
+                if (p) hipFree(p);
+            for (float *p : l.w_last_fused)
                 if (p) hipFree(p);
             if (l.bias) hipFree(l.bias);
         }
@@ -172,6 +176,8 @@ int split_terms(const w2xc_opts &o)
 }
 int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 ? 1 : 0; }
 
+bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
+
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     if (o.kernel == W2XC_KERNEL_DIRECT) return W2XC_K_DIRECT;
@@ -183,7 +189,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
         if (k == W2XC_K_MFMA) return l > 0 ? W2XC_K_MID_SPLIT : W2XC_K_DIRECT;
         if (k == W2XC_K_FIRST && l == 0)
             return (n > 1 && w2xc_pick_kernel(m->layers[1].nin, m->layers[1].nout) == W2XC_K_MFMA) ? W2XC_K_FIRST_SPLIT : W2XC_K_FIRST;
-        if (k == W2XC_K_LAST && l == n - 1 && l > 0) return W2XC_K_LAST;
+        if (k == W2XC_K_LAST && l == n - 1 && l > 0) return fuse_last(m, o) ? W2XC_K_LAST_GATHER : W2XC_K_LAST;
         return W2XC_K_DIRECT;   // run_rows rejects this
     }
     if (o.precision == W2XC_PRECISION_BF16) {
@@ -197,11 +203,25 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
     return k;
 }
 
+// Two-term modes: the last layer (cin in {32,64,128} -> ONE plane) is computed inside the epilogue of the mid layer
+// before it (conv3x3_split, out_terms = 9) and finished by conv3x3_last_gather.  W2XC_SPLIT_FUSE_LAST=0 disables.
+bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
+{
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("W2XC_SPLIT_FUSE_LAST"); en = (e && atoi(e) == 0) ? 0 : 1; }
+    const int n = (int)m->layers.size();
+    if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
+    if (o.precision != W2XC_PRECISION_BF16X2 && o.precision != W2XC_PRECISION_FP16X2) return false;
+    return m->layers[n - 1].nout == 1 && w2xc_pick_kernel(m->layers[n - 1].nin, 1) == W2XC_K_LAST &&
+           w2xc_pick_kernel(m->layers[n - 2].nin, m->layers[n - 2].nout) == W2XC_K_MFMA && n - 2 > 0;
+}
+
 // terms of layer l's OUTPUT in the split pipeline: T when layer l+1 is a split mid layer, else 0 (fp32)
 int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     const int T = split_terms(o), n = (int)m->layers.size();
     if (T == 0 || l + 1 >= n) return 0;
+    if (l == n - 2 && fuse_last(m, o)) return 9;
     return layer_kind(m, l + 1, o) == W2XC_K_MID_SPLIT ? T : 0;
 }
 
@@ -296,6 +316,20 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         }
         d.wpk = dl.w_split[wi];
         d.acc_scale = 1.0f / dl.split_scale[wi];
+        if (d.out_terms == 9) {   // the next (last) layer's weights ride along
+            DevLayer &nl = c->layers[l + 1];
+            const int nin = m->layers[l + 1].nin;
+            if (!nl.w_last_fused[d.fmt]) {
+                std::vector<float> pk((w2xc_split_pack_last_bytes(nin) + 3) / 4);
+                nl.last_fused_scale[d.fmt] = w2xc_split_pack_last(nin, d.fmt, m->layers[l + 1].w.data(), pk.data());
+                int rc = upload(pk, &nl.w_last_fused[d.fmt]);
+                if (rc) return rc;
+            }
+            d.w7pk = nl.w_last_fused[d.fmt];
+            d.g_scale = 1.0f / nl.last_fused_scale[d.fmt];
+        }
+    } else if (kind == W2XC_K_LAST_GATHER) {
+        d.wpk = nullptr;
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
     }
@@ -304,6 +338,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
     hipError_t e = kind == W2XC_K_MID_SPLIT     ? w2xc_launch_split_mid(d, st)
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
+                   : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -351,14 +386,14 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     auto out_bpe = [&](int k) -> size_t {
         if (bf16) return 2;
         const int ot = out_terms_of(m, k - 1, o);
-        return ot ? 2 * (size_t)ot : 4;
+        return (ot == 2 || ot == 3) ? 2 * (size_t)ot : 4;
     };
 
     // the last layer stores straight into the caller's planar plane(s) when its kernel can address planar
     // output (conv3x3_last / conv3x3_direct); otherwise it goes through the NHWC workspace + a repack
     const W2xcKernelKind last_kind = layer_kind(m, n - 1, o);
     const bool last_direct = (m->layers[n - 1].nout == 1 || all_out) &&
-                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_BF16IN || last_kind == W2XC_K_DIRECT ||
+                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_GATHER || last_kind == W2XC_K_LAST_BF16IN || last_kind == W2XC_K_DIRECT ||
                               (m->layers[n - 1].nout == 1 && last_kind != W2XC_K_MFMA && last_kind != W2XC_K_FIRST));
     // BYTES per band for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
     auto ws_need = [&](int rows, size_t need[2]) {
@@ -366,7 +401,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         for (int k = 1; k <= n; k++) {
             if (k == n && last_direct) break;   // written straight to d_out
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
-            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * m->layers[k - 1].nout * out_bpe(k));
+            const bool fused = T > 0 && out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
+            const size_t px_bytes = fused ? (size_t)w2xc_split_halves(m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
+            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * px_bytes);
         }
     };
     int band = o.band_rows;
@@ -401,6 +438,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         const int y1 = std::min(rb, y0 + band);
         const float *src = d_in;
         long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs, src_ts = 0, src_gs = 0;
+        int src_halves = 0;
         int src_h = vh, src_w = w;
         for (int k = 1; k <= n; k++) {
             if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
@@ -418,6 +456,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             int split_grp = 0;
             if (T > 0) {
                 d.terms = (kind == W2XC_K_MID_SPLIT) ? T : 0;
+                if (kind == W2XC_K_LAST_GATHER) d.halves = src_halves;
                 d.fmt = split_fmt(o);
                 d.in_ts = src_ts;
                 d.out_terms = out_terms_of(m, k - 1, o);
@@ -433,7 +472,13 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             } else {
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
-                if (T > 0 && d.out_terms > 0) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
+                if (T > 0 && (d.out_terms == 2 || d.out_terms == 3)) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
+                if (T > 0 && d.out_terms == 9) {   // G[half][tap][y][x]
+                    d.out_rs = d.out_w; d.out_ps = 1;
+                    d.out_gs = (long long)d.out_h * d.out_w;
+                    d.out_ts = 9 * d.out_gs;
+                    d.halves = w2xc_split_halves(hl.nout);
+                }
             }
             int rc = launch_layer(c, m, k - 1, kind, d, st, o.profile != 0);
             if (rc) return rc;
@@ -443,7 +488,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                                                   (long long)out_stride_f, 1, out_cs, d.out_h, d.out_w, all_out ? hl.nout : 1, st);
                 if (e != hipSuccess) return fail(W2XC_ERR_HIP, "repack launch failed: %s", hipGetErrorString(e));
             }
-            src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs;
+            src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs; src_halves = d.halves;
             src_h = d.out_h; src_w = d.out_w;
         }
     }

@@ -32,6 +32,12 @@ struct W2xcConvDesc {
     long long in_ts, out_ts, in_gs, out_gs;
     int fmt;             // 0 = bf16 terms, 1 = fp16 terms (W2XC_PRECISION_FP16X2)
     float acc_scale;     // fp16: 1 / (power-of-two weight scale of this layer), applied to the accumulators
+    // out_terms = 9: the LAST layer (cout = 1) is computed inside this layer's epilogue; `out` receives its partial sums
+    // G[half][tap][y][x] fp32 (out_ts = half stride, out_gs = tap-plane stride, out_rs = row stride, in floats) and
+    // W2XC_K_LAST_GATHER adds halves and taps (in = G, in_ts / in_gs / in_rs as written, `halves` halves).
+    const void *w7pk;    // last layer's weights as MFMA A fragments (w2xc_split_pack_last)
+    float g_scale;       // fp16: 1 / (power-of-two scale of the last layer's weights)
+    int halves;
 };
 
 enum W2xcKernelKind {
@@ -46,6 +52,7 @@ enum W2xcKernelKind {
     // W2XC_PRECISION_BF16X2 / BF16X3 (and BF16 through the same pipeline): fp32 values carried as d.terms bf16 terms
     W2XC_K_MID_SPLIT = 7,      // cin, cout in {32,64,128}: term planes in, term planes (or fp32 when out_terms = 0) out
     W2XC_K_FIRST_SPLIT = 8,    // W2XC_K_FIRST storing d.out_terms term planes
+    W2XC_K_LAST_GATHER = 9,    // sums the partial G planes of a fused W2XC_K_MID_SPLIT (out_terms = 9) into the output plane
 };
 
 // Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
@@ -67,6 +74,11 @@ size_t w2xc_split_packed_bytes(int cin, int cout, int terms);
 float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, void *dst);   // returns the weight scale (1 for bf16)
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream);
+// last layer fused into a two-term mid layer
+int w2xc_split_halves(int cout);
+size_t w2xc_split_pack_last_bytes(int cin);
+float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst);
+hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream);
 
 // strided element copy (planar <-> NHWC repack at the Model::filter boundary)
 hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, long long s_cs,

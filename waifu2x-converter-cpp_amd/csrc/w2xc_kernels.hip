@@ -831,6 +831,7 @@ const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout)
     case W2XC_K_LAST_BF16IN: return "conv3x3_last<bf16 in>";
     case W2XC_K_MID_SPLIT: return "conv3x3_split";
     case W2XC_K_FIRST_SPLIT: return "conv3x3_first_split";
+    case W2XC_K_LAST_GATHER: return "conv3x3_last_gather";
     default: return "conv3x3_direct";
     }
 }

@@ -69,7 +69,7 @@ static __device__ __forceinline__ unsigned pk_f16(float a, float b)
 template <int OT, int FMT>
 static __device__ __forceinline__ void store_terms(float *out, long long elem_off, long long out_ts, float v0, float v1, float v2, float v3)
 {
-    if (OT == 0) {
+    if (OT == 0 || OT == 9) {   // (OT == 9, the fused-last-layer epilogue, never gets here)
         *reinterpret_cast<f32x4 *>(out + elem_off) = (f32x4){v0, v1, v2, v3};
     } else {
         bf16_t *o16 = reinterpret_cast<bf16_t *>(out) + elem_off;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr int LOOK = RING - 3;                    // stages whose transfers are younger than B(t+2) at the end of stage t
     constexpr int LASTA = 10 - RING < 5 ? 10 - RING : 5;   // A pieces of the next slice are issued on taps 0..LASTA: landed by the end of tap 7,
                                                            // because tap 8's last step already reads the next slice's first fragments
-    constexpr int NST = MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
+    constexpr int NST = OT == 9 ? MB * 5 : MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
     static_assert((NW == 4 || NW == 8) && (ROWS == 8 || ROWS == 16) && NB * WN == NBT, "tile shape");
     static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
     static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
@@ -212,6 +212,13 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     // bias[COUT] sits behind the weight ring; lane (li, kk) reads the 4 channels of a register quad as one b128
     constexpr unsigned BIAS_BASE = B_BASE + RING * B_BYTES;
     for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c];   // visible after the prologue barrier
+    // OT == 9 (last layer fused into this epilogue): its weights as MFMA A fragments, [term][plane block][k-group][lane][8]
+    constexpr unsigned W7_BASE = BIAS_BASE + COUT * 4;
+    if constexpr (OT == 9) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(d.w7pk);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(const_cast<char *>(ldsb) + W7_BASE);
+        for (int i = threadIdx.x; i < 2 * NBT * 2 * 64; i += NW * 64) dst[i] = src[i];
+    }
 
     // ---- per-lane DMA source offsets of the A halo tile, in 16-byte units (8 bf16) ----
     const u32x4 *in4 = reinterpret_cast<const u32x4 *>(d.in);
@@ -465,7 +472,85 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 const int c = (nb0 + nb) * 32 + 8 * i + 4 * kk;
                 return obase + (long long)mb * d.out_rs + (long long)(c / SLC) * d.out_gs + c % SLC;
             };
-            if (interior) {
+            if constexpr (OT == 9) {
+                // ---- the last layer (cin = COUT -> 1 plane, 3x3) inside this epilogue, "taps as rows":
+                //   G[tap][pixel] = sum over this wave's channels of W7[tap][c] * act[c][pixel]  on the same 16-bit MFMA.
+                // The accumulator registers already ARE a B operand: lane (pixel, kk), registers 8h .. 8h+7 of a plane
+                // block hold 8 of the 16 channels of k-group h (16h + 4kk + {0..3, 8..11}); the weight fragments were
+                // packed with the same channel order.  Activations are split into two terms exactly like stored
+                // ones; products (lo,hi), (hi,hi), (hi,lo).  Each wave column (wn) writes its partial G as 9 tap planes
+                // [half][tap][y][x] (128-byte runs per store) and conv3x3_last_gather adds the halves and the taps.
+                static_assert(T == 2, "fused last layer: two-term modes only");
+                u32x4 w7[2][NB][2];
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            w7[t][nb][h] = *reinterpret_cast<const u32x4 *>(ldsb + W7_BASE + ((((t * NBT + nb0 + nb) * 2 + h) * 64 + lane) * 16));
+                const bool xin = ox0 + li < d.out_w;
+                float *gbase = d.out + (long long)wn * d.out_ts + (long long)(4 * kk) * d.out_gs + (long long)(oy0 + wm * MB) * d.out_rs + (ox0 + li);
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) {
+                    f32x16 g;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) g[r] = 0.0f;
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            float a[8];
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 16 * h + 8 * q + 4 * kk) * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = 8 * h + 4 * q + e;
+                                    const float s = (FMT ? acc[mb][nb][r] * d.acc_scale : acc[mb][nb][r]) + bq[e];
+                                    float v = fmaxf(s, 0.1f * s);
+                                    if (FMT) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+                                    a[4 * q + e] = v;
+                                    acc[mb][nb][r] = 0.0f;
+                                }
+                            }
+                            u32x4 hi, lo;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const unsigned ph = FMT ? pk_f16(a[2 * u], a[2 * u + 1]) : pk_bf16(a[2 * u], a[2 * u + 1]);
+                                float r0, r1;
+                                if (FMT) {
+                                    const f32x2 b = __builtin_convertvector(__builtin_bit_cast(h16x2_t, ph), f32x2);
+                                    r0 = a[2 * u] - b[0];
+                                    r1 = a[2 * u + 1] - b[1];
+                                } else {
+                                    r0 = a[2 * u] - __uint_as_float(ph << 16);
+                                    r1 = a[2 * u + 1] - __uint_as_float(ph & 0xFFFF0000u);
+                                }
+                                hi[u] = ph;
+                                lo[u] = FMT ? pk_f16(r0, r1) : pk_bf16(r0, r1);
+                            }
+                            if constexpr (FMT == 1) {
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[0][nb][h]), __builtin_bit_cast(h16x8, lo), g, 0, 0, 0);
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[0][nb][h]), __builtin_bit_cast(h16x8, hi), g, 0, 0, 0);
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[1][nb][h]), __builtin_bit_cast(h16x8, hi), g, 0, 0, 0);
+                            } else {
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[0][nb][h]), __builtin_bit_cast(bf16x8, lo), g, 0, 0, 0);
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[0][nb][h]), __builtin_bit_cast(bf16x8, hi), g, 0, 0, 0);
+                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[1][nb][h]), __builtin_bit_cast(bf16x8, hi), g, 0, 0, 0);
+                            }
+                        }
+                    // rows of g held by lane (pixel, kk): registers 0..3 = taps 4kk .. 4kk+3, register 4 = tap 8 (kk = 0)
+                    const float gs = FMT ? d.g_scale : 1.0f;
+                    float *gp = gbase + (long long)mb * d.out_rs;
+                    if (interior || (xin && (oy0 + wm * MB + mb < d.out_h))) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) gp[(long long)e * d.out_gs] = g[e] * gs;
+                        if (kk == 0) gp[8 * d.out_gs] = g[4] * gs;
+                    }
+                }
+                epi_stores = interior;
+            } else if (interior) {
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -595,6 +680,94 @@ __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int t
 // host side
 // ================================================================================================
 #if W2XC_SPLIT_T == 3   // shared host code lives in one object
+// ---- last layer fused into the epilogue of the two-term kernels (out_terms = 9) ----
+// conv3x3_last_gather: out(y,x) = leaky(bias + sum over taps (ty,tx) and wave-column halves of G[half][tap][y+ty][x+tx]),
+// G = [halves][9][gh][gw] fp32 tap planes as written by conv3x3_split<.., OT = 9>; (gh, gw) = (out_h + 2, out_w + 2).
+__global__ void __launch_bounds__(256) conv3x3_last_gather(const float *G, int halves, long long hs, long long ps, long long rs,
+                                                           const float *bias, float *out, long long out_rs, long long out_ps, int out_h, int out_w)
+{
+    const long long total = (long long)out_h * out_w;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int y = (int)(idx / out_w), x = (int)(idx - (long long)y * out_w);
+        float v = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const float *g = G + tap * ps + (long long)(y + tap / 3) * rs + (x + tap % 3);
+            for (int hf = 0; hf < halves; hf++) v += g[hf * hs];
+        }
+        out[(long long)y * out_rs + (long long)x * out_ps] = leaky(v + bias[0]);
+    }
+}
+
+hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    const long long total = (long long)d.out_h * d.out_w;
+    int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(conv3x3_last_gather, dim3(grid), dim3(256), 0, stream, d.in, d.halves, d.in_ts, d.in_gs, d.in_rs, d.bias, d.out,
+                       d.out_rs, d.out_ps, d.out_h, d.out_w);
+    return hipGetLastError();
+}
+
+// wave columns (WN) of the two-term tile shape for `cout` planes = partial-G planes the fused epilogue writes
+int w2xc_split_halves(int cout) { return cout >= 64 ? 2 : 1; }
+
+size_t w2xc_split_pack_last_bytes(int cin) { return (size_t)2 * (cin / 32) * 2 * 64 * 8 * 2; }
+
+// w7pk[term][plane block][k-group h][lane][8] = term of S * W[0][c][tap = lane & 31] (0 for taps >= 9), with
+// c = 32*block + 16*h + 4*(lane>>5) + (e < 4 ? e : 4 + e)   -- the channel order of the accumulator registers 8h .. 8h+7.
+// Same scale rule as w2xc_split_pack.  w is [1][cin][3][3].
+float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst)
+{
+    auto bf = [](float f) -> unsigned short {
+        unsigned u;
+        memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    };
+    auto bf2f = [](unsigned short h) -> float {
+        const unsigned u = (unsigned)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    float scale = 1.0f;
+    if (fmt == 1) {
+        float mx = 0.0f;
+        for (int i = 0; i < 9 * cin; i++) mx = fabsf(w[i]) > mx ? fabsf(w[i]) : mx;
+        if (mx > 0.0f && mx < INFINITY) {
+            int e = 0;
+            frexpf(mx, &e);
+            scale = ldexpf(1.0f, 15 - e);
+        }
+    }
+    const int nbt = cin / 32;
+    unsigned short *d16 = static_cast<unsigned short *>(dst);
+    for (int nb = 0; nb < nbt; nb++)
+        for (int h = 0; h < 2; h++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 8; e++) {
+                    const int tap = lane & 31, kk = lane >> 5;
+                    const int c = 32 * nb + 16 * h + 4 * kk + (e < 4 ? e : 4 + e);
+                    float r = tap < 9 ? w[(size_t)c * 9 + tap] * scale : 0.0f;
+                    for (int t = 0; t < 2; t++) {
+                        unsigned short hv;
+                        float back;
+                        if (fmt == 1) {
+                            const _Float16 hf = (_Float16)r;
+                            memcpy(&hv, &hf, 2);
+                            back = (float)hf;
+                        } else {
+                            hv = bf(r);
+                            back = bf2f(hv);
+                        }
+                        d16[((((size_t)t * nbt + nb) * 2 + h) * 64 + lane) * 8 + e] = hv;
+                        r -= back;
+                    }
+                }
+    return scale;
+}
+
 int w2xc_split_kg(int terms, int cin) { (void)terms; (void)cin; return 1; }   // 16-channel slices = channel groups of the layout
 
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
@@ -664,7 +837,8 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     const int ntiles = tiles_x * tiles_y;
     constexpr int NW = WM * WN;
     constexpr int A_PIECES = T * NPIXP * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
-    constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4;
+    constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4 +
+                                 (OT == 9 ? 4 * (COUT / 32) * 1024 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
@@ -731,13 +905,15 @@ static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream
 #if W2XC_SPLIT_T == 2
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
 {
-    return d.out_terms == 2 ? launch_split_t<2, 2, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 0>(d, stream) : hipErrorInvalidValue;
+    return d.out_terms == 2 ? launch_split_t<2, 2, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 0>(d, stream)
+         : d.out_terms == 9 ? launch_split_t<2, 9, 0>(d, stream) : hipErrorInvalidValue;
 }
 hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 0>(d, stream); }
 #elif W2XC_SPLIT_T == 4   // fp16 x 2
 hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream)
 {
-    return d.out_terms == 2 ? launch_split_t<2, 2, 1>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 1>(d, stream) : hipErrorInvalidValue;
+    return d.out_terms == 2 ? launch_split_t<2, 2, 1>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 1>(d, stream)
+         : d.out_terms == 9 ? launch_split_t<2, 9, 1>(d, stream) : hipErrorInvalidValue;
 }
 hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 1>(d, stream); }
 #else
