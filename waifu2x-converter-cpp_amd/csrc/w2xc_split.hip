@@ -1,30 +1,31 @@
-// w2xc_split.hip -- "split-bf16" kernels for gfx950: the 3x3xCinxCout contraction of Model::filterWorker
-// (/root/reference/src/modelHandler.cpp:117-159) on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense, 16x the fp32
-// MFMA rate of CDNA4) with every fp32 operand carried as a sum of T bf16 terms:
+// w2xc_split.hip -- "split" kernels for gfx950: the 3x3xCinxCout contraction of Model::filterWorker
+// (/root/reference/src/modelHandler.cpp:117-159) on the 16-bit MFMAs (v_mfma_f32_32x32x16_bf16 / _f16: 2.5 PFLOP/s
+// dense, 16x the fp32 MFMA rate of CDNA4) with every fp32 operand carried as a sum of T 16-bit terms:
 //
-//     a = a0 + a1 (+ a2),  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (round to nearest even)
+//     a = a0 + a1 (+ a2),  a0 = rnd16(a), a1 = rnd16(a - a0), a2 = rnd16(a - a0 - a1)      (round to nearest even)
 //     a*b ~= sum of the NP largest term products, accumulated in fp32 inside the matrix core
 //
-//     T = 1                            1 product   8-bit operands (template only: W2XC_PRECISION_BF16 has its own
-//                                                  kernels in w2xc_kernels.hip, this pipeline measured no faster)
-//     T = 2  (W2XC_PRECISION_BF16X2)   3 products  a0b0 + a0b1 + a1b0:            ~16-bit operands, |err| ~ 2^-17 |ab|
-//     T = 3  (W2XC_PRECISION_BF16X3)   6 products  + a1b1 + a0b2 + a2b0:          ~24-bit operands, |err| ~ 2^-24 |ab|,
-//                                                                                  i.e. the error level of an fp32 FMA chain
-//     T = 2, fp16 terms (W2XC_PRECISION_FP16X2, FMT = 1)  3 products on v_mfma_f32_32x32x16_f16: ~22-bit operands;
-//            weights pre-scaled per layer by a power of two (w2xc_split_pack), activations clamped to +-65504
+//     T = 2 bf16  (W2XC_PRECISION_BF16X2)  3 products  a1b0 + a0b0 + a0b1            ~16-bit operands, |err| ~ 2^-17 |ab|
+//     T = 3 bf16  (W2XC_PRECISION_BF16X3)  6 products  + a1b1 + a2b0 + a0b2          ~24-bit operands, |err| ~ 2^-24 |ab|,
+//                                                                                    the error level of an fp32 FMA chain
+//     T = 2 fp16  (W2XC_PRECISION_FP16X2, FMT = 1)  3 products                       ~22-bit operands; weights pre-scaled per
+//                 layer by a power of two (w2xc_split_pack), activations clamped to +-65504
+//     (T = 1 compiles but is not instantiated: W2XC_PRECISION_BF16 keeps its own kernels in w2xc_kernels.hip.)
 //
-// Activations between the layers are T bf16 "term planes" (`ts` elements apart), each channel-group blocked:
-// element (c, y, x) at (c / G)*gs + y*rs + x*G + c % G with G = 16*KG = the consumer's K-slice, so the halo tile
-// of one (slice, term) is contiguous per row.  The producer's epilogue does the split once per element, so the
-// consumer streams ready-made bf16 fragments with LDS-DMA exactly like conv3x3_mfma2 streams fp32 ones.  The mid layer that feeds the last layer writes plain fp32 NHWC, so
-// conv3x3_last is used unchanged.
+// Activations between the layers are T "term planes" (`ts` elements apart), each channel-group blocked:
+// element (c, y, x) at (c / 16)*gs + y*rs + x*16 + c % 16, so the halo tile of one (16-channel slice, term) is
+// contiguous per row.  The producer's epilogue does the split once per element, so the consumer streams ready-made
+// 16-bit fragments with LDS-DMA exactly like conv3x3_mfma2 streams fp32 ones.
 //
-//   conv3x3_split        cin, cout in {32,64,128}: persistent workgroups (one per CU), tile = 8 rows x 32 pixels x COUT.
-//                        Stage = (slice of 16*KG channels, tap); LDS = A[2] (halo tile of one slice, all T terms,
-//                        32*KG bytes per pixel per term, 16-byte chunks XOR-swizzled so ds_read_b128 of 32 consecutive
-//                        pixels is conflict-free) + a ring of RING B stages (T*KG*COUT/32 KiB each, fragment order).
+//   conv3x3_split        cin, cout in {32,64,128}: persistent workgroups (one per CU), tile = 8 or 16 rows x 32 pixels
+//                        x COUT.  Stage = (16-channel slice, tap); LDS = A[2] (halo tile of one slice, all T terms, 32
+//                        bytes per pixel per term, the two 16-byte chunks XOR-swizzled so ds_read_b128 of 32 consecutive
+//                        pixels is conflict-free) + a ring of RING B stages (T*COUT/32 KiB each, fragment order) + bias.
 //                        Operands are swapped (weights = MFMA A operand): the accumulator tile is [channel][pixel],
 //                        lane = pixel, 4 consecutive channels per register quad -> 8/16-byte stores, no LDS transpose.
+//                        OT = T: term planes out; OT = 0: fp32 NHWC out (feeds conv3x3_last); OT = 9 (two terms): the
+//                        one-plane LAST layer is computed in the epilogue from the accumulator registers and its partial
+//                        tap planes go to conv3x3_last_gather.
 //   conv3x3_first_split  cin <= 3 (layer 1) on the fp32 MFMA exactly like conv3x3_first, storing term planes.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
@@ -99,7 +100,7 @@ static __device__ __forceinline__ void store_terms(float *out, long long elem_of
     }
 }
 
-// term products in issue order (smallest first): activation term PA[i] x weight term PB[i]
+// term products in issue order: activation term a(i) x weight term b(i)
 template <int T> struct Prod;
 template <> struct Prod<1> {
     static constexpr int N = 1;
