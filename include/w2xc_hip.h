@@ -39,8 +39,9 @@ typedef struct w2xc_model w2xc_model;
 #define W2XC_PRECISION_FP32 0   /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-f32 fma chains        */
 #define W2XC_PRECISION_BF16 1   /* w2xc_convert_* only: activations BETWEEN layers are bf16 (RNE), layers
                                  * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
-                                 * accumulate, bias and LeakyReLU; first / last layer arithmetic stays
-                                 * fp32.  Not the reference's arithmetic: tolerance in DESIGN.md 4.  */
+                                 * accumulate, bias and LeakyReLU; the first layer stays fp32, a one-plane
+                                 * last layer is fused into layer n-1 with 16-bit-accurate split products.
+                                 * Not the reference's arithmetic: tolerance in DESIGN.md 4.          */
 #define W2XC_PRECISION_BF16X2 2 /* w2xc_convert_* only: split-bf16.  Every fp32 activation / weight of layers
                                  * 2..n-1 is carried as the sum of 2 bf16 terms (hi + lo, ~16 mantissa bits)
                                  * and each product is 3 bf16 MFMA products accumulated in fp32.          */

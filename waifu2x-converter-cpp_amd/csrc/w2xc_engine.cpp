@@ -172,6 +172,11 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
 // bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline)
 int split_terms(const w2xc_opts &o)
 {
+    if (o.precision == W2XC_PRECISION_BF16) {   // plain bf16 = the same pipeline with ONE term; W2XC_BF16_PIPE=v1 selects
+        static int v = -1;                      // the first-generation kernels (conv3x3_mfma_bf16, NHWC bf16 activations)
+        if (v < 0) { const char *e = getenv("W2XC_BF16_PIPE"); v = (e && !strcmp(e, "v1")) ? 0 : 1; }
+        return v;
+    }
     return (o.precision == W2XC_PRECISION_BF16X2 || o.precision == W2XC_PRECISION_FP16X2) ? 2 : o.precision == W2XC_PRECISION_BF16X3 ? 3 : 0;
 }
 int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 ? 1 : 0; }
@@ -211,7 +216,8 @@ bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
     if (en < 0) { const char *e = getenv("W2XC_SPLIT_FUSE_LAST"); en = (e && atoi(e) == 0) ? 0 : 1; }
     const int n = (int)m->layers.size();
     if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
-    if (o.precision != W2XC_PRECISION_BF16X2 && o.precision != W2XC_PRECISION_FP16X2) return false;
+    const int T = split_terms(o);
+    if (T != 1 && T != 2) return false;
     return m->layers[n - 1].nout == 1 && w2xc_pick_kernel(m->layers[n - 1].nin, 1) == W2XC_K_LAST &&
            w2xc_pick_kernel(m->layers[n - 2].nin, m->layers[n - 2].nout) == W2XC_K_MFMA && n - 2 > 0;
 }
@@ -306,7 +312,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         if (rc) return rc;
     }
     if (kind == W2XC_K_MID_SPLIT) {
-        if (d.terms < 2 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
+        if (d.terms < 1 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
         const int wi = d.terms + 3 * d.fmt;
         if (!dl.w_split[wi]) {
             std::vector<float> pk((w2xc_split_packed_bytes(d.cin, d.cout, d.terms) + 3) / 4);
@@ -386,7 +392,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     auto out_bpe = [&](int k) -> size_t {
         if (bf16) return 2;
         const int ot = out_terms_of(m, k - 1, o);
-        return (ot == 2 || ot == 3) ? 2 * (size_t)ot : 4;
+        return (ot >= 1 && ot <= 3) ? 2 * (size_t)ot : 4;
     };
 
     // the last layer stores straight into the caller's planar plane(s) when its kernel can address planar
@@ -402,7 +408,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (k == n && last_direct) break;   // written straight to d_out
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
             const bool fused = T > 0 && out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
-            const size_t px_bytes = fused ? (size_t)w2xc_split_halves(m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
+            const size_t px_bytes = fused ? (size_t)w2xc_split_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * px_bytes);
         }
     };
@@ -472,12 +478,12 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             } else {
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
-                if (T > 0 && (d.out_terms == 2 || d.out_terms == 3)) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
+                if (T > 0 && d.out_terms >= 1 && d.out_terms <= 3) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
                 if (T > 0 && d.out_terms == 9) {   // G[half][tap][y][x]
                     d.out_rs = d.out_w; d.out_ps = 1;
                     d.out_gs = (long long)d.out_h * d.out_w;
                     d.out_ts = 9 * d.out_gs;
-                    d.halves = w2xc_split_halves(hl.nout);
+                    d.halves = w2xc_split_halves(T, hl.nout);
                 }
             }
             int rc = launch_layer(c, m, k - 1, kind, d, st, o.profile != 0);

@@ -38,7 +38,7 @@
 #include <type_traits>
 
 #ifndef W2XC_SPLIT_T
-#error "compile with -DW2XC_SPLIT_T=2, 3 or 4 (= fp16 x 2): one object per variant, see the Makefile"
+#error "compile with -DW2XC_SPLIT_T=1, 2, 3 or 4 (= fp16 x 2): one object per variant, see the Makefile"
 #endif
 #ifndef W2XC_SPLIT_LATE
 #define W2XC_SPLIT_LATE 4   // MFMAs kept after the last fragment read of a step
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr int NCH = 2 * KG;                       // 16-byte chunks per pixel per term in one slice
     constexpr int PXB = 32 * KG;                      // bytes per pixel per term
     constexpr int SWS = NCH == 2 ? 3 : NCH == 4 ? 2 : 1;   // swizzle: chunk q of pixel p sits at q ^ ((p >> SWS) & (NCH-1))
-    constexpr int SLC = 16 * KG;                      // channels per slice = channel-group size of the blocked layout
+    constexpr int GRP = 16;                           // channel-group size of the blocked term-plane layout
+    constexpr int SLC = GRP * KG;                     // channels per slice (KG groups: chunk q of a pixel lives in group q >> 1)
     constexpr int NSL = CIN / SLC, NBT = COUT / 32;
     constexpr int NW = WM * WN;
     constexpr unsigned A_TERM = NPIXP * PXB;          // bytes of one term of the halo tile (pixels padded to whole 1 KiB pieces)
@@ -215,7 +216,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c];   // visible after the prologue barrier
     // OT == 9 (last layer fused into this epilogue): its weights as MFMA A fragments, [term][plane block][k-group][lane][8]
     constexpr unsigned W7_BASE = BIAS_BASE + COUT * 4;
-    if constexpr (OT == 9) {
+    constexpr bool W7_IN_LDS = (T == 2);   // (the one-term shapes have no LDS left: fragments come from L2 instead)
+    if constexpr (OT == 9 && W7_IN_LDS) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(d.w7pk);
         u32x4 *dst = reinterpret_cast<u32x4 *>(const_cast<char *>(ldsb) + W7_BASE);
         for (int i = threadIdx.x; i < 2 * NBT * 2 * 64; i += NW * 64) dst[i] = src[i];
@@ -240,13 +242,13 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
         int t, p, q;
         slot_of(jj, t, p, q);
         const int py = p / HW, px = p - py * HW;
-        lofs[jj] = (unsigned)t * ts16 + (unsigned)(((long long)py * d.in_rs + (long long)px * SLC) >> 3) + q;
+        lofs[jj] = (unsigned)t * ts16 + (unsigned)(q >> 1) * gs16 + (unsigned)(((long long)py * d.in_rs + (long long)px * GRP) >> 3) + (q & 1);
     }
     auto tile_offsets = [&](int tl) {
         const int ty_ = tl / tiles_x, tx_ = tl - ty_ * tiles_x;
         const int y0 = ty_ * ROWS + d.off_y, x0 = tx_ * 32 + d.off_x;
         if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
-            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * SLC) >> 3);
+            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * GRP) >> 3);
 #pragma unroll
             for (int jj = 0; jj < APW; jj++) goff[jj] = lofs[jj] + base;
             return;
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             const int py = p / HW, px = p - py * HW;
             const int gy = clampi(y0 + py, 0, d.in_h - 1);
             const int gx = clampi(x0 + px, 0, d.in_w - 1);
-            goff[jj] = (unsigned)t * ts16 + (unsigned)(((long long)gy * d.in_rs + (long long)gx * SLC) >> 3) + q;
+            goff[jj] = (unsigned)t * ts16 + (unsigned)(q >> 1) * gs16 + (unsigned)(((long long)gy * d.in_rs + (long long)gx * GRP) >> 3) + (q & 1);
         }
     };
     auto dma_a = [&](unsigned add, unsigned abuf, int jj) {
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     for (;;) {
         // what the A pieces issued during this slice fetch: the next slice, or the next tile's first
         const bool last_slice = (sl == NSL - 1);
-        unsigned a_add = (unsigned)(sl + 1) * gs16;
+        unsigned a_add = (unsigned)(sl + 1) * KG * gs16;
         if (last_slice) {
             tile_offsets(tile + per < chunk_end ? tile + per : tile);
             a_add = 0;
@@ -465,13 +467,13 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
             const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
             // fp32 out: NHWC.  Term planes: channel-group blocked, element (t, c, y, x) at
-            //   t*ts + (c / SLC)*gs + y*rs + x*SLC + c % SLC   (the layout the next layer's A tiles stream from)
+            //   t*ts + (c / 16)*gs + y*rs + x*16 + c % 16   (the layout the next layer's A tiles stream from)
             const long long obase = OT == 0 ? (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * COUT + nb0 * 32 + 4 * kk
-                                            : (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * SLC;
+                                            : (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * GRP;
             auto oofs = [&](int mb, int nb, int i) -> long long {   // element offset of channels (nb0+nb)*32 + 8i + 4kk .. +3
                 if (OT == 0) return obase + (long long)mb * d.out_rs + nb * 32 + 8 * i;
                 const int c = (nb0 + nb) * 32 + 8 * i + 4 * kk;
-                return obase + (long long)mb * d.out_rs + (long long)(c / SLC) * d.out_gs + c % SLC;
+                return obase + (long long)mb * d.out_rs + (long long)(c / GRP) * d.out_gs + c % GRP;
             };
             if constexpr (OT == 9) {
                 // ---- the last layer (cin = COUT -> 1 plane, 3x3) inside this epilogue, "taps as rows":
@@ -479,9 +481,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 // The accumulator registers already ARE a B operand: lane (pixel, kk), registers 8h .. 8h+7 of a plane
                 // block hold 8 of the 16 channels of k-group h (16h + 4kk + {0..3, 8..11}); the weight fragments were
                 // packed with the same channel order.  Activations are split into two terms exactly like stored
-                // ones; products (lo,hi), (hi,hi), (hi,lo).  Each wave column (wn) writes its partial G as 9 tap planes
+                // ones (also in the one-term mode: the fp32 accumulators are at hand); products (lo,hi), (hi,hi), (hi,lo).  Each wave column (wn) writes its partial G as 9 tap planes
                 // [half][tap][y][x] (128-byte runs per store) and conv3x3_last_gather adds the halves and the taps.
-                static_assert(T == 2, "fused last layer: two-term modes only");
+                static_assert(T == 1 || T == 2, "fused last layer: one- and two-term modes");
                 u32x4 w7[2][NB][2];
 #pragma unroll
                 for (int t = 0; t < 2; t++)
@@ -489,7 +491,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
                         for (int h = 0; h < 2; h++)
-                            w7[t][nb][h] = *reinterpret_cast<const u32x4 *>(ldsb + W7_BASE + ((((t * NBT + nb0 + nb) * 2 + h) * 64 + lane) * 16));
+                            w7[t][nb][h] = W7_IN_LDS ? *reinterpret_cast<const u32x4 *>(ldsb + W7_BASE + ((((t * NBT + nb0 + nb) * 2 + h) * 64 + lane) * 16))
+                                                     : reinterpret_cast<const u32x4 *>(d.w7pk)[((t * NBT + nb0 + nb) * 2 + h) * 64 + lane];
                 const bool xin = ox0 + li < d.out_w;
                 float *gbase = d.out + (long long)wn * d.out_ts + (long long)(4 * kk) * d.out_gs + (long long)(oy0 + wm * MB) * d.out_rs + (ox0 + li);
 #pragma unroll
@@ -711,7 +714,7 @@ hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
 }
 
 // wave columns (WN) of the two-term tile shape for `cout` planes = partial-G planes the fused epilogue writes
-int w2xc_split_halves(int cout) { return cout >= 64 ? 2 : 1; }
+int w2xc_split_halves(int terms, int cout) { return terms == 1 ? (cout >= 128 ? 2 : 1) : (cout >= 64 ? 2 : 1); }
 
 size_t w2xc_split_pack_last_bytes(int cin) { return (size_t)2 * (cin / 32) * 2 * 64 * 8 * 2; }
 
@@ -769,7 +772,9 @@ float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst)
     return scale;
 }
 
-int w2xc_split_kg(int terms, int cin) { (void)terms; (void)cin; return 1; }   // 16-channel slices = channel groups of the layout
+// k-groups (16-channel layout groups) per stage: one for the two/three-term modes; the one-term mode has a third of
+// the MFMAs per byte and takes 64-channel stages to amortise the stage barrier
+int w2xc_split_kg(int terms, int cin) { return terms == 1 ? (cin >= 64 ? 4 : 2) : 1; }
 
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms) { return (size_t)9 * cin * cout * 2 * terms; }
 
@@ -839,7 +844,7 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     constexpr int NW = WM * WN;
     constexpr int A_PIECES = T * NPIXP * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
     constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4 +
-                                 (OT == 9 ? 4 * (COUT / 32) * 1024 : 0);
+                                 ((OT == 9 && T == 2) ? 4 * (COUT / 32) * 1024 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
@@ -865,8 +870,24 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
 template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
-    constexpr int KG = 1, RG = 6;
     constexpr bool BIG = (T == 2);
+    if constexpr (T == 1) {   // one term: 8 rows x 32 px, 4 waves, 64-channel stages (32 for cin = 32), ring of 4
+        switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+        case 32032:  return launch_split<32, 32, 2, 1, 4, 1, 1, OT, 2, 4, FMT>(d, stream);
+        case 32064:  return launch_split<32, 64, 2, 2, 4, 1, 1, OT, 2, 4, FMT>(d, stream);
+        case 32128:  return launch_split<32, 128, 4, 2, 2, 2, 1, OT, 2, 4, FMT>(d, stream);
+        case 64032:  return launch_split<64, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
+        case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
+        case 64128:  return launch_split<64, 128, 4, 2, 2, 2, 1, OT, 4, 4, FMT>(d, stream);
+        case 128032: return launch_split<128, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
+        case 128064: return launch_split<128, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
+#endif
+        case 128128: return launch_split<128, 128, 4, 2, 2, 2, 1, OT, 4, 4, FMT>(d, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    constexpr int KG = 1, RG = 6;
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                     CIN  COUT  MB NB WM WN
@@ -903,7 +924,14 @@ static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream
     return hipGetLastError();
 }
 
-#if W2XC_SPLIT_T == 2
+#if W2XC_SPLIT_T == 1
+hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream)
+{
+    return d.out_terms == 1 ? launch_split_t<1, 1, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<1, 0, 0>(d, stream)
+         : d.out_terms == 9 ? launch_split_t<1, 9, 0>(d, stream) : hipErrorInvalidValue;
+}
+hipError_t w2xc_launch_split_first_1(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<1, 0>(d, stream); }
+#elif W2XC_SPLIT_T == 2
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
 {
     return d.out_terms == 2 ? launch_split_t<2, 2, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<2, 0, 0>(d, stream)
@@ -922,11 +950,14 @@ hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_first_1(const W2xcConvDesc &d, hipStream_t stream);
 
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     if (d.in_shift != 0 || (d.in_rs & 7) || (d.in_ts & 7) || (d.in_gs & 7)) return hipErrorInvalidValue;
+    if (d.terms == 1 && d.fmt == 0) return w2xc_launch_split_mid_1(d, stream);
     if (d.terms == 2) return d.fmt == 1 ? w2xc_launch_split_mid_h(d, stream) : w2xc_launch_split_mid_2(d, stream);
     if (d.terms != 3 || d.fmt != 0) return hipErrorInvalidValue;
     return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream) : hipErrorInvalidValue;
@@ -935,6 +966,7 @@ hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.out_terms == 1 && d.fmt == 0) return w2xc_launch_split_first_1(d, stream);
     if (d.out_terms == 2) return d.fmt == 1 ? w2xc_launch_split_first_h(d, stream) : w2xc_launch_split_first_2(d, stream);
     return (d.out_terms == 3 && d.fmt == 0) ? launch_first_split_t<3, 0>(d, stream) : hipErrorInvalidValue;
 }
