@@ -25,11 +25,12 @@ def bins(w2xc):
     return REF_BIN, HIP_BIN
 
 
-def run_convert(binary, model, plane, tmp, tag, split=1):
+def run_convert(binary, model, plane, tmp, tag, split=1, env=None):
     fin, fout = str(tmp / (tag + "_in.f32")), str(tmp / (tag + "_out.f32"))
     plane.astype(np.float32).tofile(fin)
     h, w = plane.shape
-    r = subprocess.run([binary, "convert", model, fin, str(w), str(h), fout, str(split)], capture_output=True, text=True)
+    r = subprocess.run([binary, "convert", model, fin, str(w), str(h), fout, str(split)], capture_output=True, text=True,
+                       env=None if env is None else dict(os.environ, **env))
     out = np.fromfile(fout, np.float32).reshape(h, w) if r.returncode == 0 else None
     return r.returncode, out, r.stderr
 
@@ -62,6 +63,22 @@ def test_same_caller_reference_vs_hip(bins, models_dir, tmp_path, h, w, split):
     assert rc_r == 0, err_r
     assert rc_h == 0, err_h
     assert_close(hip, ref, "dropin %dx%d" % (h, w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp16x2", "bf16x3"])
+def test_same_caller_with_precision_from_environment(bins, models_dir, tmp_path, precision):
+    """the SAME binary (compiled against include/w2xc/*.hpp, no options anywhere in its source) switched to a
+    16-bit split mode by W2XC_PRECISION: still inside the fp32 tolerance against the reference build, and not
+    bit-identical to its own fp32 run (i.e. the switch took effect)."""
+    model = os.path.join(models_dir, "scale2.0x_model.json")
+    x = rand_plane(90, 120, 17)
+    rc_r, ref, err_r = run_convert(bins[0], model, x, tmp_path, "ref")
+    rc_f, f32, err_f = run_convert(bins[1], model, x, tmp_path, "hip32")
+    rc_h, hip, err_h = run_convert(bins[1], model, x, tmp_path, "hip16", env={"W2XC_PRECISION": precision})
+    assert rc_r == 0 and rc_f == 0 and rc_h == 0, (err_r, err_f, err_h)
+    assert_close(hip, ref, "dropin " + precision)
+    assert not np.array_equal(hip, f32)
 
 
 @pytest.mark.gpu
