@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080, help="input frame height (CNN plane is 2x)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-precisions", action="store_true", help="skip the informational opt-in-precision runs after the timed region")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x2", "bf16x3", "fp16x2"],
@@ -281,7 +282,7 @@ def main():
             "layers": per_layer,
             "output_finite": ok,
         }
-        if world == 1 and args.precision == "fp32" and args.workload == "scale2x_1080p":
+        if world == 1 and args.precision == "fp32" and args.workload == "scale2x_1080p" and not args.no_other_precisions:
             # the opt-in precisions on the same resident plane, right after the timed region (3 steps each): their
             # time and their distance from the fp32 result just measured.  Informational -- `value` above is fp32.
             try:

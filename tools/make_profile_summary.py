@@ -23,11 +23,11 @@ def mean_counter(path, sub, counter):
     return sum(v) / len(v) if v else None
 
 stats = {r["Name"]: r for r in csv.DictReader(open(base + "trace/trace_kernel_stats.csv"))}
-out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline%s (tools/profile.sh)" % ("" if T == 0 else " --precision " + prec),
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-precisions%s (tools/profile.sh)" % ("" if T == 0 else " --precision " + prec),
        "note": __doc__.split("FETCH_SIZE", 1)[1].strip().replace("\n", " "), "kernels": {}}
 for k, (cin, cout) in enumerate(PLANES, 1):
     if T == 0:
-        sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("<%d, %d," % (cin, cout))
+        sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_mfma2<%d, %d," % (cin, cout))
     else:
         sub = ("conv3x3_first_split<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_split<%d, %d," % (cin, cout))
         if k == NL and T == 2 and any(n.startswith("conv3x3_last_gather") for n in stats):
