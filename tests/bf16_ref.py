@@ -44,8 +44,8 @@ def _split(t, terms, dtype=torch.bfloat16):
 def convert_split_emulated(layers, plane, terms, n_in=1, fp16=False):
     """Dataflow of the split pipeline with float64 accumulation: fp32 first layer; every mid layer
     (cin, cout in {32,64,128}, not first) sums PRODUCTS[terms] of the 16-bit terms of its fp32 input and
-    weights; fp32 last layer -- except in the two-term modes, where a one-plane last layer behind a mid layer is
-    fused into that layer's epilogue and uses the same split products.  fp16=True (W2XC_PRECISION_FP16X2): fp16 terms, activations clamped to +-65504,
+    weights; a one-plane last layer behind a mid layer is fused into that layer's epilogue and uses the same split
+    products, any other last layer is fp32.  fp16=True (W2XC_PRECISION_FP16X2): fp16 terms, activations clamped to +-65504,
     weights scaled by the power of two that puts max|w| into [2^14, 2^15) and the sum scaled back.
     `plane` is (h, w) or (n_in, h, w); returns all output planes."""
     n = len(layers)
@@ -57,7 +57,7 @@ def convert_split_emulated(layers, plane, terms, n_in=1, fp16=False):
     for k, (nin, nout, w, b) in enumerate(layers):
         bias = torch.from_numpy(b.astype(np.float32)).to(torch.float64)
         wt = torch.from_numpy(w)
-        fused_last = (terms == 2 and n >= 3 and k == n - 1 and nout == 1 and mid(nin) and mid(layers[n - 2][0]))
+        fused_last = (n >= 3 and k == n - 1 and nout == 1 and mid(nin) and mid(layers[n - 2][0]))
         if (k > 0 and mid(nin) and mid(nout)) or fused_last:   # (two-term modes compute a 1-plane last layer the same way)
             scale = 1.0
             if fp16:

@@ -695,7 +695,7 @@ def test_cli_shell_precision_flag(gpu, models_dir, tmp_path):
 
 
 def test_fused_last_layer_vs_unfused(gpu, tmp_path):
-    """two-term modes compute the one-plane last layer inside the epilogue of the layer before it (conv3x3_split
+    """the 16-bit modes compute the one-plane last layer inside the epilogue of the layer before it (conv3x3_split
     out_terms = 9 + conv3x3_last_gather).  W2XC_SPLIT_FUSE_LAST=0 restores the separate fp32 conv3x3_last: the two
     must agree to the fp32-order level on odd sizes, borders, banding and the nearest-2x entry point."""
     import subprocess, sys
@@ -706,7 +706,7 @@ def test_fused_last_layer_vs_unfused(gpu, tmp_path):
         "w = g.load_package(); outs = []; flags = []\n"
         "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 1], 7), ([1, 64, 32, 1], 8)):\n"
         "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
-        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2):\n"
+        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2, w.PRECISION_BF16X3):\n"
         "        for (h, wd) in ((37, 61), (8, 32), (130, 70)):\n"
         "            x = np.random.default_rng(h).random((h, wd), dtype=np.float32)\n"
         "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec)).ravel())\n"

@@ -69,8 +69,8 @@ struct DevLayer {
     float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
-    float *w_last_fused[2] = {nullptr, nullptr};   // w2xc_split_pack_last image per format (bf16 / fp16), packed on first use
-    float last_fused_scale[2] = {1, 1};
+    float *w_last_fused[3] = {nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms
+    float last_fused_scale[3] = {1, 1, 1};
     float *bias = nullptr;
 };
 
@@ -208,7 +208,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
     return k;
 }
 
-// Two-term modes: the last layer (cin in {32,64,128} -> ONE plane) is computed inside the epilogue of the mid layer
+// 16-bit modes: the last layer (cin in {32,64,128} -> ONE plane) is computed inside the epilogue of the mid layer
 // before it (conv3x3_split, out_terms = 9) and finished by conv3x3_last_gather.  W2XC_SPLIT_FUSE_LAST=0 disables.
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
 {
@@ -217,7 +217,7 @@ bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
     const int n = (int)m->layers.size();
     if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
     const int T = split_terms(o);
-    if (T != 1 && T != 2) return false;
+    if (T < 1 || T > 3) return false;
     return m->layers[n - 1].nout == 1 && w2xc_pick_kernel(m->layers[n - 1].nin, 1) == W2XC_K_LAST &&
            w2xc_pick_kernel(m->layers[n - 2].nin, m->layers[n - 2].nout) == W2XC_K_MFMA && n - 2 > 0;
 }
@@ -325,14 +325,15 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         if (d.out_terms == 9) {   // the next (last) layer's weights ride along
             DevLayer &nl = c->layers[l + 1];
             const int nin = m->layers[l + 1].nin;
-            if (!nl.w_last_fused[d.fmt]) {
-                std::vector<float> pk((w2xc_split_pack_last_bytes(nin) + 3) / 4);
-                nl.last_fused_scale[d.fmt] = w2xc_split_pack_last(nin, d.fmt, m->layers[l + 1].w.data(), pk.data());
-                int rc = upload(pk, &nl.w_last_fused[d.fmt]);
+            const int lt = d.terms == 3 ? 3 : 2, li = d.terms == 3 ? 2 : d.fmt;
+            if (!nl.w_last_fused[li]) {
+                std::vector<float> pk((w2xc_split_pack_last_bytes(nin, lt) + 3) / 4);
+                nl.last_fused_scale[li] = w2xc_split_pack_last(nin, lt, d.fmt, m->layers[l + 1].w.data(), pk.data());
+                int rc = upload(pk, &nl.w_last_fused[li]);
                 if (rc) return rc;
             }
-            d.w7pk = nl.w_last_fused[d.fmt];
-            d.g_scale = 1.0f / nl.last_fused_scale[d.fmt];
+            d.w7pk = nl.w_last_fused[li];
+            d.g_scale = 1.0f / nl.last_fused_scale[li];
         }
     } else if (kind == W2XC_K_LAST_GATHER) {
         d.wpk = nullptr;

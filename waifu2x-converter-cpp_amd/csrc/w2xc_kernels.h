@@ -76,8 +76,8 @@ hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream);
 // last layer fused into a two-term mid layer
 int w2xc_split_halves(int terms, int cout);
-size_t w2xc_split_pack_last_bytes(int cin);
-float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst);
+size_t w2xc_split_pack_last_bytes(int cin, int terms);   // terms = 2 (one- and two-term modes) or 3
+float w2xc_split_pack_last(int cin, int terms, int fmt, const float *w, void *dst);
 hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream);
 
 // strided element copy (planar <-> NHWC repack at the Model::filter boundary)

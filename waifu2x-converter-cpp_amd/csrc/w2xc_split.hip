@@ -481,12 +481,14 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 // The accumulator registers already ARE a B operand: lane (pixel, kk), registers 8h .. 8h+7 of a plane
                 // block hold 8 of the 16 channels of k-group h (16h + 4kk + {0..3, 8..11}); the weight fragments were
                 // packed with the same channel order.  Activations are split into two terms exactly like stored
-                // ones (also in the one-term mode: the fp32 accumulators are at hand); products (lo,hi), (hi,hi), (hi,lo).  Each wave column (wn) writes its partial G as 9 tap planes
+                // ones (two terms also in the one-term mode: the fp32 accumulators are at hand); same product lists as the
+                // main loop.  Each wave column (wn) writes its partial G as 9 tap planes
                 // [half][tap][y][x] (128-byte runs per store) and conv3x3_last_gather adds the halves and the taps.
-                static_assert(T == 1 || T == 2, "fused last layer: one- and two-term modes");
-                u32x4 w7[2][NB][2];
+                // LT = terms of the fused product: 2 (3 products) for the one- and two-term modes, 3 (6 products) for BF16X3.
+                constexpr int LT = T == 3 ? 3 : 2;
+                u32x4 w7[LT][NB][2];
 #pragma unroll
-                for (int t = 0; t < 2; t++)
+                for (int t = 0; t < LT; t++)
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
@@ -518,31 +520,33 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                                     acc[mb][nb][r] = 0.0f;
                                 }
                             }
-                            u32x4 hi, lo;
+                            u32x4 xt[LT];   // activation terms of this k-group as B operands
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const unsigned ph = FMT ? pk_f16(a[2 * u], a[2 * u + 1]) : pk_bf16(a[2 * u], a[2 * u + 1]);
-                                float r0, r1;
-                                if (FMT) {
-                                    const f32x2 b = __builtin_convertvector(__builtin_bit_cast(h16x2_t, ph), f32x2);
-                                    r0 = a[2 * u] - b[0];
-                                    r1 = a[2 * u + 1] - b[1];
-                                } else {
-                                    r0 = a[2 * u] - __uint_as_float(ph << 16);
-                                    r1 = a[2 * u + 1] - __uint_as_float(ph & 0xFFFF0000u);
+                            for (int t = 0; t < LT; t++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const unsigned ph = FMT ? pk_f16(a[2 * u], a[2 * u + 1]) : pk_bf16(a[2 * u], a[2 * u + 1]);
+                                    xt[t][u] = ph;
+                                    if (t + 1 < LT) {
+                                        if (FMT) {
+                                            const f32x2 b = __builtin_convertvector(__builtin_bit_cast(h16x2_t, ph), f32x2);
+                                            a[2 * u] -= b[0];
+                                            a[2 * u + 1] -= b[1];
+                                        } else {
+                                            a[2 * u] -= __uint_as_float(ph << 16);
+                                            a[2 * u + 1] -= __uint_as_float(ph & 0xFFFF0000u);
+                                        }
+                                    }
                                 }
-                                hi[u] = ph;
-                                lo[u] = FMT ? pk_f16(r0, r1) : pk_bf16(r0, r1);
-                            }
-                            if constexpr (FMT == 1) {
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[0][nb][h]), __builtin_bit_cast(h16x8, lo), g, 0, 0, 0);
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[0][nb][h]), __builtin_bit_cast(h16x8, hi), g, 0, 0, 0);
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[1][nb][h]), __builtin_bit_cast(h16x8, hi), g, 0, 0, 0);
-                            } else {
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[0][nb][h]), __builtin_bit_cast(bf16x8, lo), g, 0, 0, 0);
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[0][nb][h]), __builtin_bit_cast(bf16x8, hi), g, 0, 0, 0);
-                                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[1][nb][h]), __builtin_bit_cast(bf16x8, hi), g, 0, 0, 0);
-                            }
+                            static_for<0, Prod<LT>::N>([&](auto PI) {
+                                constexpr int pi = decltype(PI)::value;
+                                if constexpr (FMT == 1)
+                                    g = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, w7[Prod<LT>::b(pi)][nb][h]),
+                                                                               __builtin_bit_cast(h16x8, xt[Prod<LT>::a(pi)]), g, 0, 0, 0);
+                                else
+                                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w7[Prod<LT>::b(pi)][nb][h]),
+                                                                                __builtin_bit_cast(bf16x8, xt[Prod<LT>::a(pi)]), g, 0, 0, 0);
+                            });
                         }
                     // rows of g held by lane (pixel, kk): registers 0..3 = taps 4kk .. 4kk+3, register 4 = tap 8 (kk = 0)
                     const float gs = FMT ? d.g_scale : 1.0f;
@@ -714,14 +718,14 @@ hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
 }
 
 // wave columns (WN) of the two-term tile shape for `cout` planes = partial-G planes the fused epilogue writes
-int w2xc_split_halves(int terms, int cout) { return terms == 1 ? (cout >= 128 ? 2 : 1) : (cout >= 64 ? 2 : 1); }
+int w2xc_split_halves(int terms, int cout) { return terms == 2 ? (cout >= 64 ? 2 : 1) : (cout >= 128 ? 2 : 1); }
 
-size_t w2xc_split_pack_last_bytes(int cin) { return (size_t)2 * (cin / 32) * 2 * 64 * 8 * 2; }
+size_t w2xc_split_pack_last_bytes(int cin, int terms) { return (size_t)terms * (cin / 32) * 2 * 64 * 8 * 2; }
 
-// w7pk[term][plane block][k-group h][lane][8] = term of S * W[0][c][tap = lane & 31] (0 for taps >= 9), with
+// w7pk[term < terms][plane block][k-group h][lane][8] = term of S * W[0][c][tap = lane & 31] (0 for taps >= 9), with
 // c = 32*block + 16*h + 4*(lane>>5) + (e < 4 ? e : 4 + e)   -- the channel order of the accumulator registers 8h .. 8h+7.
 // Same scale rule as w2xc_split_pack.  w is [1][cin][3][3].
-float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst)
+float w2xc_split_pack_last(int cin, int terms, int fmt, const float *w, void *dst)
 {
     auto bf = [](float f) -> unsigned short {
         unsigned u;
@@ -754,7 +758,7 @@ float w2xc_split_pack_last(int cin, int fmt, const float *w, void *dst)
                     const int tap = lane & 31, kk = lane >> 5;
                     const int c = 32 * nb + 16 * h + 4 * kk + (e < 4 ? e : 4 + e);
                     float r = tap < 9 ? w[(size_t)c * 9 + tap] * scale : 0.0f;
-                    for (int t = 0; t < 2; t++) {
+                    for (int t = 0; t < terms; t++) {
                         unsigned short hv;
                         float back;
                         if (fmt == 1) {
@@ -960,7 +964,8 @@ hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
     if (d.terms == 1 && d.fmt == 0) return w2xc_launch_split_mid_1(d, stream);
     if (d.terms == 2) return d.fmt == 1 ? w2xc_launch_split_mid_h(d, stream) : w2xc_launch_split_mid_2(d, stream);
     if (d.terms != 3 || d.fmt != 0) return hipErrorInvalidValue;
-    return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream) : hipErrorInvalidValue;
+    return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream)
+         : d.out_terms == 9 ? launch_split_t<3, 9, 0>(d, stream) : hipErrorInvalidValue;
 }
 
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
