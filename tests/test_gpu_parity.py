@@ -750,3 +750,36 @@ def test_bf16_first_generation_kernels_still_work(gpu, tmp_path):
         seen[pipe] = name
         assert err <= 2e-2 and 10 * np.log10(1.0 / mse) >= 45.0, (pipe, err, mse)
     assert seen == {"v1": "conv3x3_mfma_bf16", "split": "conv3x3_split"}, seen
+
+
+def test_fused_first_two_layers_vs_unfused(gpu, tmp_path):
+    """the 16-bit modes run layers 1 (1 -> 32) and 2 (32 -> C) as ONE kernel (conv3x3_first2_split: layer 1's terms stay in
+    LDS).  It uses the same arithmetic in the same order as conv3x3_first_split + conv3x3_split, so with
+    W2XC_SPLIT_FUSE_FIRST=0 the results must be BIT-IDENTICAL -- odd sizes, borders, banding, nearest-2x, every precision."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "w = g.load_package(); outs = []; flags = []\n"
+        "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 32, 1], 7), ([1, 32, 128, 64, 1], 8), ([1, 32, 32, 3], 9)):\n"
+        "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
+        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2, w.PRECISION_BF16X3, w.PRECISION_BF16):\n"
+        "        if planes[-1] != 1: continue\n"
+        "        for (h, wd) in ((37, 61), (8, 32), (130, 70)):\n"
+        "            x = np.random.default_rng(h).random((h, wd), dtype=np.float32)\n"
+        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec)).ravel())\n"
+        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec, band_rows=11)).ravel())\n"
+        "            outs.append(ms.convert_nn2x(x, w.make_opts(precision=prec)).ravel())\n"
+        "    flags.append(float(ms.kernel_name(1, w.make_opts(precision=w.PRECISION_FP16X2)) == 'conv3x3_first2_split'))\n"
+        "np.save(sys.argv[1], np.concatenate(outs + [np.array(flags)]))\n" % ROOT)
+    res = []
+    for fuse in ("1", "0"):
+        f = str(tmp_path / ("o%s.npy" % fuse))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_SPLIT_FUSE_FIRST=fuse), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        res.append(np.load(f))
+    a, b = res
+    assert a.shape == b.shape
+    assert (a[-4:] == 1.0).all() and (b[-4:] == 0.0).all()          # the fused kernel really ran (and really did not)
+    assert np.array_equal(a[:-4], b[:-4])

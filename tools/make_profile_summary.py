@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX> [fp32|bf16x2|bf16x3|fp16x2]
+"""tools/make_profile_summary.py <gpurun_out/prof_TAG> <profiles/PREFIX> [fp32|bf16x2|bf16x3|fp16x2|bf16]
 Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries:
   PREFIX_kernel_stats.csv  (rocprofv3 --kernel-trace --stats)
   PREFIX_pmc_summary.txt   (per-kernel means of every PMC counter)
@@ -9,8 +9,8 @@ FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE reports 1/2 of wide streaming
 import csv, json, os, shutil, subprocess, sys
 base, prefix = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
-T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3, "fp16x2": 2}[prec]
-PRODUCTS = {0: 1, 2: 3, 3: 6}[T]
+T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3, "fp16x2": 2, "bf16": 1}[prec]
+PRODUCTS = {0: 1, 1: 1, 2: 3, 3: 6}[T]
 H, W, NL = 2160, 3840, 7
 PLANES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)]
 shutil.copy(base + "trace/trace_kernel_stats.csv", prefix + "_kernel_stats.csv")
@@ -30,7 +30,12 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         sub = ("conv3x3_first<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_mfma2<%d, %d," % (cin, cout))
     else:
         sub = ("conv3x3_first_split<%d," % cin) if k == 1 else ("conv3x3_last<%d, %d" % (cin, cout)) if k == NL else ("conv3x3_split<%d, %d," % (cin, cout))
-        if k == NL and T == 2 and any(n.startswith("conv3x3_last_gather") for n in stats):
+        fused12 = any("conv3x3_first2_split" in n for n in stats)
+        if fused12 and k == 1:
+            continue                                   # computed inside layer 2's kernel
+        if fused12 and k == 2:
+            sub = "conv3x3_first2_split<%d," % cout   # layers 1 + 2 in one kernel
+        if k == NL and any(n.startswith("conv3x3_last_gather") for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
     if not names:
@@ -46,7 +51,9 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     alg = (cin * in_bpe + cout * out_bpe) * px
     if sub == "conv3x3_last_gather":
         alg = (2 * 9 * 4 + 4) * px                      # two halves of 9 tap planes in, one plane out
-    if T == 2 and k == NL - 1 and any(n.startswith("conv3x3_last_gather") for n in stats):
+    if T > 0 and k == 2 and any("conv3x3_first2_split" in n for n in stats):
+        alg = (4 + cout * out_bpe) * px                 # reads the input plane, layer 1's activations never reach HBM
+    if T > 0 and k == NL - 1 and any(n.startswith("conv3x3_last_gather") for n in stats):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px,
          "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,

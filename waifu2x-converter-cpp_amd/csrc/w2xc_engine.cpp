@@ -182,6 +182,7 @@ int split_terms(const w2xc_opts &o)
 int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 ? 1 : 0; }
 
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
+bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
@@ -191,6 +192,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
     if (split_terms(o) > 0) {
         // term planes live only BETWEEN a first/mid layer and a mid layer; everything that touches the
         // caller's planes or the last layer is fp32.  Shapes without an MFMA kernel are unsupported.
+        if (l <= 1 && fuse_first(m, o)) return l == 0 ? W2XC_K_FUSED_AWAY : W2XC_K_FIRST2_SPLIT;
         if (k == W2XC_K_MFMA) return l > 0 ? W2XC_K_MID_SPLIT : W2XC_K_DIRECT;
         if (k == W2XC_K_FIRST && l == 0)
             return (n > 1 && w2xc_pick_kernel(m->layers[1].nin, m->layers[1].nout) == W2XC_K_MFMA) ? W2XC_K_FIRST_SPLIT : W2XC_K_FIRST;
@@ -206,6 +208,19 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
         return W2XC_K_DIRECT;   // run_rows rejects this for bf16
     }
     return k;
+}
+
+// 16-bit modes: layers 1 (ONE plane -> 32) and 2 (32 -> {32,64,128}) run as one kernel (conv3x3_first2_split) when
+// layer 2 is an ordinary split mid layer.  W2XC_SPLIT_FUSE_FIRST=0 disables.
+bool fuse_first(const w2xc_model *m, const w2xc_opts &o)
+{
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("W2XC_SPLIT_FUSE_FIRST"); en = (e && atoi(e) == 0) ? 0 : 1; }
+    const int n = (int)m->layers.size();
+    if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3 || split_terms(o) == 0) return false;
+    if (m->layers[0].nin != 1 || m->layers[0].nout != 32) return false;
+    if (w2xc_pick_kernel(m->layers[1].nin, m->layers[1].nout) != W2XC_K_MFMA) return false;
+    return !(n == 3 && fuse_last(m, o));   // (layer 2 would be the fused-last producer: keep that fusion instead)
 }
 
 // 16-bit modes: the last layer (cin in {32,64,128} -> ONE plane) is computed inside the epilogue of the mid layer
@@ -311,7 +326,8 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         int rc = upload(pk, &dl.w_bf16);
         if (rc) return rc;
     }
-    if (kind == W2XC_K_MID_SPLIT) {
+    if (kind == W2XC_K_FUSED_AWAY) return W2XC_OK;   // computed by the next layer's W2XC_K_FIRST2_SPLIT launch
+    if (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) {
         if (d.terms < 1 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
         const int wi = d.terms + 3 * d.fmt;
         if (!dl.w_split[wi]) {
@@ -322,6 +338,10 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         }
         d.wpk = dl.w_split[wi];
         d.acc_scale = 1.0f / dl.split_scale[wi];
+        if (kind == W2XC_K_FIRST2_SPLIT) {
+            d.w1pk = c->layers[l - 1].w_fast;
+            d.bias1 = c->layers[l - 1].bias;
+        }
         if (d.out_terms == 9) {   // the next (last) layer's weights ride along
             DevLayer &nl = c->layers[l + 1];
             const int nin = m->layers[l + 1].nin;
@@ -346,6 +366,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     hipError_t e = kind == W2XC_K_MID_SPLIT     ? w2xc_launch_split_mid(d, st)
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
+                   : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -407,6 +428,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         need[0] = need[1] = 0;
         for (int k = 1; k <= n; k++) {
             if (k == n && last_direct) break;   // written straight to d_out
+            if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
             const bool fused = T > 0 && out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
             const size_t px_bytes = fused ? (size_t)w2xc_split_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
@@ -446,6 +468,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         const float *src = d_in;
         long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs, src_ts = 0, src_gs = 0;
         int src_halves = 0;
+        W2xcConvDesc first_d;
+        memset(&first_d, 0, sizeof first_d);
         int src_h = vh, src_w = w;
         for (int k = 1; k <= n; k++) {
             if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
@@ -460,9 +484,18 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.off_x = k == 1 ? -n : 0;
             d.in_shift = k == 1 ? up : 0;
             const W2xcKernelKind kind = layer_kind(m, k - 1, o);
+            if (kind == W2XC_K_FUSED_AWAY) {   // layer 1 inside layer 2's kernel: keep its input description for that launch
+                first_d = d;
+                continue;
+            }
+            if (kind == W2XC_K_FIRST2_SPLIT) {
+                d.in = first_d.in; d.in_rs = first_d.in_rs; d.in_ps = first_d.in_ps; d.in_cs = first_d.in_cs;
+                d.in_h = first_d.in_h; d.in_w = first_d.in_w;
+                d.off_y = first_d.off_y; d.off_x = first_d.off_x; d.in_shift = first_d.in_shift;
+            }
             int split_grp = 0;
             if (T > 0) {
-                d.terms = (kind == W2XC_K_MID_SPLIT) ? T : 0;
+                d.terms = (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) ? T : 0;
                 if (kind == W2XC_K_LAST_GATHER) d.halves = src_halves;
                 d.fmt = split_fmt(o);
                 d.in_ts = src_ts;

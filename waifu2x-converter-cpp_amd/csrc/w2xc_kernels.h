@@ -35,6 +35,10 @@ struct W2xcConvDesc {
     // out_terms = 9: the LAST layer (cout = 1) is computed inside this layer's epilogue; `out` receives its partial sums
     // G[half][tap][y][x] fp32 (out_ts = half stride, out_gs = tap-plane stride, out_rs = row stride, in floats) and
     // W2XC_K_LAST_GATHER adds halves and taps (in = G, in_ts / in_gs / in_rs as written, `halves` halves).
+    // W2XC_K_FIRST2_SPLIT (layers 1 + 2 in one kernel): `in` / in_* / off_* / in_shift describe LAYER 1's input plane,
+    // wpk / bias / acc_scale / terms / fmt / out_* layer 2; layer 1's own weights (W2XC_K_FIRST image) and bias:
+    const float *w1pk;
+    const float *bias1;
     const void *w7pk;    // last layer's weights as MFMA A fragments (w2xc_split_pack_last)
     float g_scale;       // fp16: 1 / (power-of-two scale of the last layer's weights)
     int halves;
@@ -53,6 +57,8 @@ enum W2xcKernelKind {
     W2XC_K_MID_SPLIT = 7,      // cin, cout in {32,64,128}: term planes in, term planes (or fp32 when out_terms = 0) out
     W2XC_K_FIRST_SPLIT = 8,    // W2XC_K_FIRST storing d.out_terms term planes
     W2XC_K_LAST_GATHER = 9,    // sums the partial G planes of a fused W2XC_K_MID_SPLIT (out_terms = 9) into the output plane
+    W2XC_K_FIRST2_SPLIT = 10,  // layers 1 (1 -> 32) and 2 (32 -> {32,64,128}) in one kernel; launched in layer 2's slot
+    W2XC_K_FUSED_AWAY = 11,    // layer 1 when W2XC_K_FIRST2_SPLIT computes it: no launch
 };
 
 // Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
@@ -74,6 +80,7 @@ size_t w2xc_split_packed_bytes(int cin, int cout, int terms);
 float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, void *dst);   // returns the weight scale (1 for bf16)
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_first2_split(const W2xcConvDesc &d, hipStream_t stream);
 // last layer fused into a two-term mid layer
 int w2xc_split_halves(int terms, int cout);
 size_t w2xc_split_pack_last_bytes(int cin, int terms);   // terms = 2 (one- and two-term modes) or 3

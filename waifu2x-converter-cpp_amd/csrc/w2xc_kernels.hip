@@ -832,6 +832,8 @@ const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout)
     case W2XC_K_MID_SPLIT: return "conv3x3_split";
     case W2XC_K_FIRST_SPLIT: return "conv3x3_first_split";
     case W2XC_K_LAST_GATHER: return "conv3x3_last_gather";
+    case W2XC_K_FIRST2_SPLIT: return "conv3x3_first2_split";
+    case W2XC_K_FUSED_AWAY: return "(in_next_layer)";
     default: return "conv3x3_direct";
     }
 }

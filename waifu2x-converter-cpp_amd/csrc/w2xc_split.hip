@@ -684,6 +684,180 @@ __global__ void __launch_bounds__(256) conv3x3_first_split(W2xcConvDesc d, int t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_first2_split: layers 1 AND 2 in one kernel (layer 1 = 1 -> 32 planes, layer 2 = 32 -> COUT), the layer-1
+// activations never leave the CU.  Tile = 8 rows x 32 px of layer 2's output, 4 waves:
+//   1. the 12 x 36 input patch (clamp-to-edge pad and the optional nearest-2x folded in, like conv3x3_first) -> LDS;
+//   2. layer 1 on the 10 x 34 halo pixels, 32 at a time, on v_mfma_f32_32x32x2_f32 (operands swapped: lane = pixel),
+//      bias + LeakyReLU, split into T 16-bit terms, written to LDS as [term][pixel][32 channels] (64 B per pixel,
+//      16-byte chunks XOR-swizzled with bits 2..3 of the pixel index: conflict-free ds_read_b128);
+//   3. layer 2 from those terms exactly like conv3x3_split (same product order, same stage order: bit-identical
+//      results), weight fragments straight from L2 in w2xc_split_pack order, several workgroups per CU hide latency.
+// Saves layer 1's store and layer 2's load (128 / 192 B per pixel at two / three terms) and one launch.
+// ------------------------------------------------------------------------------------------------
+template <int COUT, int T, int OT, int FMT>
+__global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int tiles_x, int ntiles)
+{
+    constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2, NPIX = HH * HW, NBLK = (NPIX + 31) / 32;
+    constexpr int PW = 36, PH = HH + 2;
+    constexpr int NBT = COUT / 32, S = 5;                       // layer 1: K = 9 taps padded to 10 = 5 MFMA k-steps
+    constexpr int KGX = (T == 1) ? 2 : 1, NSLX = 2 / KGX;      // structure of layer 2's weight image (w2xc_split_pack, cin = 32)
+    constexpr int NP = Prod<T>::N;
+    constexpr unsigned ACT_BASE = 2048, ACT_TERM = NBLK * 32 * 64;
+    static_assert(PH * PW * 4 <= ACT_BASE && (OT == T || OT == 0), "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *ldsb = reinterpret_cast<char *>(lds);
+
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 5, li = lane & 31;
+
+    // ---- 1. input patch ----
+    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+        const int py = idx / PW, px = idx - py * PW;
+        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;
+        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;
+        lds[idx] = d.in[(long long)gy * d.in_rs + (long long)gx * d.in_ps];
+    }
+    float w1[S], b1[16];
+#pragma unroll
+    for (int s = 0; s < S; s++) w1[s] = d.w1pk[s * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; r++) b1[r] = d.bias1[(r & 3) + 8 * (r >> 2) + 4 * kk];
+    __syncthreads();
+
+    // ---- 2. layer 1 on the halo tile -> term planes in LDS ----
+    for (int blk = wave; blk < NBLK; blk += 4) {
+        const int p = blk * 32 + li;
+        const int pc = p < NPIX ? p : NPIX - 1;
+        const int py = pc / HW, px = pc - py * HW;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int off0 = (k0 / 3) * PW + k0 % 3, off1 = k1 < 9 ? (k1 / 3) * PW + k1 % 3 : 0;
+            const float a = lds[py * PW + px + (kk ? off1 : off0)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[s], a, acc, 0, 0, 0);   // rows = channels, columns = pixels
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v[r] = leaky(acc[r] + b1[r]);
+            if (FMT) v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+        }
+        // registers 8g + 4h + (0..3) = channels 16g + 8h + 4kk + (0..3): the kk-th 8-byte half of chunk (g, h)
+        const unsigned pbase = ACT_BASE + (unsigned)p * 64 + (unsigned)kk * 8;
+        const unsigned sw = (unsigned)(p >> 2) & 3u;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                float *q = &v[4 * c4];
+                const unsigned p01 = FMT ? pk_f16(q[0], q[1]) : pk_bf16(q[0], q[1]), p23 = FMT ? pk_f16(q[2], q[3]) : pk_bf16(q[2], q[3]);
+                *reinterpret_cast<u32x2 *>(ldsb + pbase + t * ACT_TERM + (((unsigned)c4 ^ sw) << 4)) = (u32x2){p01, p23};
+                if (t + 1 < T) {
+                    if (FMT) {
+                        const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
+                        const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
+                        q[0] -= b01[0]; q[1] -= b01[1]; q[2] -= b23[0]; q[3] -= b23[1];
+                    } else {
+                        q[0] -= __uint_as_float(p01 << 16);
+                        q[1] -= __uint_as_float(p01 & 0xFFFF0000u);
+                        q[2] -= __uint_as_float(p23 << 16);
+                        q[3] -= __uint_as_float(p23 & 0xFFFF0000u);
+                    }
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- 3. layer 2 ----
+    f32x16 acc2[MB][NBT];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[mb][nb][r] = 0.0f;
+    // 18 (k-group, tap) iterations in conv3x3_split's stage order; the weight fragments come straight from L2, loaded
+    // PF iterations ahead into a rotating register queue (the loops are fully unrolled: all indices are constants)
+    const u32x4 *w2 = reinterpret_cast<const u32x4 *>(d.wpk) + lane;
+    constexpr int NIT = 18, PF = 4;
+    // fragment byte address of (row = mb + ty, tx) for k-group 0; k-group G is the same XOR (G << 5) (chunk 2G + kk = kk ^ 2G)
+    unsigned xa[MB + 2][3];
+#pragma unroll
+    for (int row = 0; row < MB + 2; row++)
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++) {
+            const int p = (wave * MB + row) * HW + li + tx;
+            xa[row][tx] = ACT_BASE + (unsigned)p * 64 + ((((unsigned)(p >> 2) & 3u) ^ (unsigned)kk) << 4);
+        }
+    u32x4 wq[PF][T][NBT];
+    auto load_w = [&](int it) {
+        const int sl = it / (9 * KGX), tap = (it / KGX) % 9, g = it % KGX;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int nb = 0; nb < NBT; nb++) wq[it % PF][t][nb] = w2[(size_t)((((tap * NSLX + sl) * T + t) * KGX + g) * NBT + nb) * 64];
+    };
+#pragma unroll
+    for (int it = 0; it < PF - 1; it++) load_w(it);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        if (it + PF - 1 < NIT) load_w(it + PF - 1);
+        const int sl = it / (9 * KGX), tap = (it / KGX) % 9, g = it % KGX;
+        const int G = sl * KGX + g;                          // 16-channel k-group of layer 2's input
+        u32x4 x[T][MB];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+                x[t][mb] = *reinterpret_cast<const u32x4 *>(ldsb + (xa[mb + tap / 3][tap % 3] ^ (unsigned)(G << 5)) + t * ACT_TERM);
+#pragma unroll
+        for (int pi = 0; pi < NP; pi++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int nb = 0; nb < NBT; nb++) {
+                    if constexpr (FMT == 1)
+                        acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wq[it % PF][Prod<T>::b(pi)][nb]),
+                                                                              __builtin_bit_cast(h16x8, x[Prod<T>::a(pi)][mb]), acc2[mb][nb], 0, 0, 0);
+                    else
+                        acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[it % PF][Prod<T>::b(pi)][nb]),
+                                                                               __builtin_bit_cast(bf16x8, x[Prod<T>::a(pi)][mb]), acc2[mb][nb], 0, 0, 0);
+                }
+    }
+
+    // ---- epilogue of layer 2: bias + LeakyReLU, term planes (blocked) or fp32 NHWC ----
+    const int x = ox0 + li;
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        const int y = oy0 + wave * MB + mb;
+        const bool in = (y < d.out_h) && (x < d.out_w);
+#pragma unroll
+        for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int c = nb * 32 + 8 * i + 4 * kk;
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(d.bias + c);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float sacc = (FMT ? acc2[mb][nb][4 * i + e] * d.acc_scale : acc2[mb][nb][4 * i + e]) + bq[e];
+                    v[e] = fmaxf(sacc, 0.1f * sacc);
+                }
+                const long long o = OT == 0 ? (long long)y * d.out_rs + (long long)x * COUT + c
+                                            : (long long)(c / 16) * d.out_gs + (long long)y * d.out_rs + (long long)x * 16 + c % 16;
+                if (in) store_terms<OT, FMT>(d.out, o, d.out_ts, v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -909,6 +1083,41 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
     }
 }
 
+template <int COUT, int T, int OT, int FMT>
+static hipError_t launch_first2(const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+    constexpr size_t lds_bytes = 2048 + (size_t)T * 11 * 32 * 64;
+    auto kern = conv3x3_first2_split<COUT, T, OT, FMT>;
+    if (lds_bytes > 64 * 1024) {   // function attributes are per device
+        static std::atomic<unsigned long long> attr_done{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            if (dev < 64) attr_done.fetch_or(1ull << dev);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds_bytes, stream, d, tiles_x, ntiles);
+    return hipGetLastError();
+}
+
+template <int T, int FMT>
+static hipError_t launch_first2_t(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.cin != 32 || (d.out_terms != T && d.out_terms != 0)) return hipErrorInvalidValue;
+    const bool f32out = d.out_terms == 0;
+    switch (d.cout) {
+    case 32:  return f32out ? launch_first2<32, T, 0, FMT>(d, stream) : launch_first2<32, T, T, FMT>(d, stream);
+    case 64:  return f32out ? launch_first2<64, T, 0, FMT>(d, stream) : launch_first2<64, T, T, FMT>(d, stream);
+    case 128: return f32out ? launch_first2<128, T, 0, FMT>(d, stream) : launch_first2<128, T, T, FMT>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <int OT, int FMT>
 static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -935,6 +1144,7 @@ hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream)
          : d.out_terms == 9 ? launch_split_t<1, 9, 0>(d, stream) : hipErrorInvalidValue;
 }
 hipError_t w2xc_launch_split_first_1(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<1, 0>(d, stream); }
+hipError_t w2xc_launch_first2_1(const W2xcConvDesc &d, hipStream_t stream) { return launch_first2_t<1, 0>(d, stream); }
 #elif W2XC_SPLIT_T == 2
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -942,6 +1152,7 @@ hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream)
          : d.out_terms == 9 ? launch_split_t<2, 9, 0>(d, stream) : hipErrorInvalidValue;
 }
 hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 0>(d, stream); }
+hipError_t w2xc_launch_first2_2(const W2xcConvDesc &d, hipStream_t stream) { return launch_first2_t<2, 0>(d, stream); }
 #elif W2XC_SPLIT_T == 4   // fp16 x 2
 hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -949,6 +1160,7 @@ hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream)
          : d.out_terms == 9 ? launch_split_t<2, 9, 1>(d, stream) : hipErrorInvalidValue;
 }
 hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream) { return launch_first_split_t<2, 1>(d, stream); }
+hipError_t w2xc_launch_first2_h(const W2xcConvDesc &d, hipStream_t stream) { return launch_first2_t<2, 1>(d, stream); }
 #else
 hipError_t w2xc_launch_split_mid_2(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_2(const W2xcConvDesc &d, hipStream_t stream);
@@ -956,6 +1168,18 @@ hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_1(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_first2_1(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_first2_2(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_first2_h(const W2xcConvDesc &d, hipStream_t stream);
+
+// layers 1 + 2 in one kernel (d.terms / d.fmt = format of the layer-1 activations, d.cin = 32)
+hipError_t w2xc_launch_first2_split(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.terms == 1 && d.fmt == 0) return w2xc_launch_first2_1(d, stream);
+    if (d.terms == 2) return d.fmt == 1 ? w2xc_launch_first2_h(d, stream) : w2xc_launch_first2_2(d, stream);
+    return (d.terms == 3 && d.fmt == 0) ? launch_first2_t<3, 0>(d, stream) : hipErrorInvalidValue;
+}
 
 hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
 {
