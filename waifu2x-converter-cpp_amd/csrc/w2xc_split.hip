@@ -38,7 +38,7 @@
 #include <type_traits>
 
 #ifndef W2XC_SPLIT_T
-#error "compile with -DW2XC_SPLIT_T=1, 2, 3 or 4 (= fp16 x 2): one object per variant, see the Makefile"
+#error "compile with -DW2XC_SPLIT_T=1, 2, 3, 4 (= fp16 x 2) or 5 (= 3 terms, fp32 / fused-last out): one object per variant, see the Makefile"
 #endif
 #ifndef W2XC_SPLIT_LATE
 #define W2XC_SPLIT_LATE 4   // MFMAs kept after the last fragment read of a step
@@ -1137,7 +1137,12 @@ static hipError_t launch_first_split_t(const W2xcConvDesc &d, hipStream_t stream
     return hipGetLastError();
 }
 
-#if W2XC_SPLIT_T == 1
+#if W2XC_SPLIT_T == 5   // three terms, fp32 / fused-last outputs (their own object: the six-product bodies compile slowly)
+hipError_t w2xc_launch_split_mid_3x(const W2xcConvDesc &d, hipStream_t stream)
+{
+    return d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream) : d.out_terms == 9 ? launch_split_t<3, 9, 0>(d, stream) : hipErrorInvalidValue;
+}
+#elif W2XC_SPLIT_T == 1
 hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream)
 {
     return d.out_terms == 1 ? launch_split_t<1, 1, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<1, 0, 0>(d, stream)
@@ -1168,6 +1173,7 @@ hipError_t w2xc_launch_split_mid_h(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_h(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_mid_1(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_split_first_1(const W2xcConvDesc &d, hipStream_t stream);
+hipError_t w2xc_launch_split_mid_3x(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_first2_1(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_first2_2(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_first2_h(const W2xcConvDesc &d, hipStream_t stream);
@@ -1188,8 +1194,7 @@ hipError_t w2xc_launch_split_mid(const W2xcConvDesc &d, hipStream_t stream)
     if (d.terms == 1 && d.fmt == 0) return w2xc_launch_split_mid_1(d, stream);
     if (d.terms == 2) return d.fmt == 1 ? w2xc_launch_split_mid_h(d, stream) : w2xc_launch_split_mid_2(d, stream);
     if (d.terms != 3 || d.fmt != 0) return hipErrorInvalidValue;
-    return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : d.out_terms == 0 ? launch_split_t<3, 0, 0>(d, stream)
-         : d.out_terms == 9 ? launch_split_t<3, 9, 0>(d, stream) : hipErrorInvalidValue;
+    return d.out_terms == 3 ? launch_split_t<3, 3, 0>(d, stream) : w2xc_launch_split_mid_3x(d, stream);
 }
 
 hipError_t w2xc_launch_split_first(const W2xcConvDesc &d, hipStream_t stream)
