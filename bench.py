@@ -244,7 +244,7 @@ def main():
         dom_ms = layer_ms[dom] / dom_launches
         bands = nbands[dom]
         dom_flops = flops_layer[dom] / bands
-        # split-bf16: every algorithmic multiply-add is 3 (bf16x2) or 6 (bf16x3) bf16 MFMA products
+        # split modes: every algorithmic multiply-add is 3 (bf16x2, fp16x2) or 6 (bf16x3) 16-bit MFMA products
         products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "fp16x2": 3}[args.precision]
         achieved = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         per_layer = []

@@ -42,7 +42,7 @@ typedef struct w2xc_model w2xc_model;
                                  * accumulate, bias and LeakyReLU; the first layer stays fp32, a one-plane
                                  * last layer is fused into layer n-1 with 16-bit-accurate split products.
                                  * Not the reference's arithmetic: tolerance in DESIGN.md 4.          */
-#define W2XC_PRECISION_BF16X2 2 /* w2xc_convert_* only: split-bf16.  Every fp32 activation / weight of layers
+#define W2XC_PRECISION_BF16X2 2 /* w2xc_convert_* only: split products.  Every fp32 activation / weight of layers
                                  * 2..n-1 is carried as the sum of 2 bf16 terms (hi + lo, ~16 mantissa bits)
                                  * and each product is 3 bf16 MFMA products accumulated in fp32.          */
 #define W2XC_PRECISION_BF16X3 3 /* as above with 3 terms (~24 mantissa bits) and 6 products: the error level

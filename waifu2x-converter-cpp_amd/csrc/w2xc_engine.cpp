@@ -169,7 +169,7 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
     return r;
 }
 
-// bf16 terms per activation value between the layers of the split-bf16 pipeline (0 = not that pipeline)
+// 16-bit terms per activation value between the layers of the split pipeline, w2xc_split.hip (0 = not that pipeline)
 int split_terms(const w2xc_opts &o)
 {
     if (o.precision == W2XC_PRECISION_BF16) {   // plain bf16 = the same pipeline with ONE term; W2XC_BF16_PIPE=v1 selects
@@ -408,7 +408,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     if (T > 0)
         for (int l = 0; l < n; l++)
             if (layer_kind(m, l, o) == W2XC_K_DIRECT)
-                return fail(W2XC_ERR_UNSUPPORTED, "split-bf16 precision: layer %d (%d->%d) has no kernel ({1,3}->{32,64,128} first, {32,64,128}->{32,64,128}, ->{1,3} last only)",
+                return fail(W2XC_ERR_UNSUPPORTED, "16-bit precision modes: layer %d (%d->%d) has no kernel ({1,3}->{32,64,128} first, {32,64,128}->{32,64,128}, ->{1,3} last only)",
                             l + 1, m->layers[l].nin, m->layers[l].nout);
     // bytes per activation element of layer k's output (k = 1..n) in the workspace
     auto out_bpe = [&](int k) -> size_t {

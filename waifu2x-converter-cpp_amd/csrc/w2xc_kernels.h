@@ -25,7 +25,7 @@ struct W2xcConvDesc {
     // in UPSCALED coordinates, memory is addressed at (y >> in_shift, x >> in_shift).  0 or 1; only the
     // first-layer kernels (conv3x3_first, conv3x3_direct) honour it.
     int in_shift;
-    // split-bf16 kernels (w2xc_split.hip): an activation tensor is `terms` bf16 term planes, each channel-group
+    // split kernels (w2xc_split.hip): an activation tensor is `terms` 16-bit (bf16 / fp16) term planes, each channel-group
     // blocked: element (t, c, y, x) at t*ts + (c / G)*gs + y*rs + x*G + c % G  (ELEMENTS; G = 16).
     // out_terms = 0 stores plain fp32 NHWC.
     int terms, out_terms;
@@ -73,7 +73,7 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 // Enqueue one layer on `stream`.  Returns hipSuccess or the launch error.
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream);
 
-// split-bf16 kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` bf16 terms of every weight in
+// split kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` 16-bit terms of every weight in
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.
 int w2xc_split_kg(int terms, int cin);
 size_t w2xc_split_packed_bytes(int cin, int cout, int terms);
