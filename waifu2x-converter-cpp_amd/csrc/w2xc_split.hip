@@ -805,19 +805,27 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
 #pragma unroll
             for (int nb = 0; nb < NBT; nb++) wq[it % PF][t][nb] = w2[(size_t)((((tap * NSLX + sl) * T + t) * KGX + g) * NBT + nb) * 64];
     };
-#pragma unroll
-    for (int it = 0; it < PF - 1; it++) load_w(it);
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        if (it + PF - 1 < NIT) load_w(it + PF - 1);
+    constexpr int PFX = 2;                                    // activation fragments are read PFX iterations ahead
+    u32x4 xq[PFX + 1][T][MB];
+    auto load_x = [&](int it) {
         const int sl = it / (9 * KGX), tap = (it / KGX) % 9, g = it % KGX;
         const int G = sl * KGX + g;                          // 16-channel k-group of layer 2's input
-        u32x4 x[T][MB];
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
-                x[t][mb] = *reinterpret_cast<const u32x4 *>(ldsb + (xa[mb + tap / 3][tap % 3] ^ (unsigned)(G << 5)) + t * ACT_TERM);
+                xq[it % (PFX + 1)][t][mb] = *reinterpret_cast<const u32x4 *>(ldsb + (xa[mb + tap / 3][tap % 3] ^ (unsigned)(G << 5)) + t * ACT_TERM);
+    };
+#pragma unroll
+    for (int it = 0; it < PF - 1; it++) load_w(it);
+#pragma unroll
+    for (int it = 0; it < PFX; it++) load_x(it);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        if (it + PF - 1 < NIT) load_w(it + PF - 1);
+        if (it + PFX < NIT) load_x(it + PFX);
+        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetches above this iteration's MFMAs
+        auto &x = xq[it % (PFX + 1)];
 #pragma unroll
         for (int pi = 0; pi < NP; pi++)
 #pragma unroll
