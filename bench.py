@@ -5,32 +5,44 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one convertWithModels pass (7 layers: pad-7 by clamped loads, 7 kernel launches,
-crop/stitch in the last kernel's store) over one frame per GPU:
+A "step" is one convertWithModels pass (7 layers: pad-7 by clamped loads, 7 kernel launches, crop/stitch
+in the last kernel's store) over one batch of synthetic input:
 
-  workload "scale2x_1080p" (BASELINE.json configs[1]): synthetic 1920x1080 RGB frame -> luma
-  Y = 0.299R + 0.587G + 0.114B on /255 floats -> nearest-neighbour 2x (main.cpp:132-140) ->
-  CNN plane 2160x3840 fp32, scale2.0x topology 1-32-32-64-64-128-128-1 with seeded synthetic
-  weights (the shipped JSON models are stripped from the reference; see oracle/gen_model.py).
+  N = 1   workload "scale2x_1080p" (BASELINE.json configs[1]): a synthetic 1920x1080 RGB frame -> luma
+          Y = 0.299R + 0.587G + 0.114B on /255 floats -> nearest-neighbour 2x (main.cpp:132-140) -> CNN plane
+          2160x3840 fp32, scale2.0x topology 1-32-32-64-64-128-128-1 with seeded synthetic weights (the shipped
+          JSON models are stripped from the reference; tools/gen_model.py).
+  N > 1   workload "plane" (BASELINE.json configs[2]): ONE synthetic 8192x8192 RGB frame whose 16384x16384 CNN
+          plane is cut into N contiguous row ranges, one per rank (the reference's block walk,
+          convertRoutine.cpp:84-169, made parallel; ranks never exchange data, the host is the gather):
+          "scaling": "strong".  The weak-scaling figure (every rank its own 1080p frame) is reported beside it
+          as `weak`.  The N = 1 line carries the one-GPU time of the same 8192x8192 plane (`plane_8192`) so the
+          strong-scaling efficiency can be computed against the identical workload.
 
-Input and output planes are resident in HBM when the timed region starts (device-pointer entry
-point w2xc_convert_plane_device); `value` is whole-job input-image Mpix/s = N * 1920*1080 * K / t
-(the CNN runs on 4x as many pixels).  Multi-GPU: one process per GPU, every rank converts its own
-frame (the path shards into independent frames / row bands, no collective on the data path), so
-per-GPU work is fixed: "scaling": "weak".  torch.distributed (RCCL) is used only for the barrier
-and the MAX over ranks of the elapsed time.
+`value` (the bench contract: inputs resident in HBM when the timed region starts) times the device-pointer entry
+point over K steps, bracketed by barrier + synchronize, MAX over ranks, no profiling events in the region.
+`host_to_host` is SURVEY 8(d)'s definition of end-to-end -- the convertWithModels call with a HOST Y plane in and a
+HOST plane out (pad, H2D, layers, D2H, stitch; pageable numpy planes, median of the per-call wall times), i.e. what
+/root/reference/src/main.cpp:96,148 measures around its call -- and its ratio to `value`; PCIe-inclusive, so by the
+contract it is reported beside `value`, never as `value`.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = layer 6 (conv3x3_mfma, 128->128, 51% of the FLOPs): algorithmic
-               FLOPs of one launch / its average duration from hipEvents recorded on the launch
-               stream inside the timed region (w2xc_opts.profile), vs the 157.3 TFLOP/s fp32 MFMA peak.
-  cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real
-               binary cannot be built) timed on this host's cores on a bounded sample of whole 512^2
-               blocks of the same plane (the reference's block-split path costs the same per block).
+  roofline     dominant kernel = layer 6 (conv3x3_mfma2, 128->128, 51% of the FLOPs): algorithmic FLOPs of one
+               launch / its average duration from hipEvents recorded on the launch stream (w2xc_opts.profile) in a
+               second pass of the same K steps right after the timed region (so the events are not inside
+               `value`'s region; `ms_per_step_profiled` shows they cost nothing), vs the 157.3 TFLOP/s fp32 MFMA peak.
+               `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same command
+               (profiles/r2_roofline.json), only when that profile was taken from the kernel sources being run
+               (hash check), else null.
+  cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real binary cannot be
+               built) timed on this host's cores on a bounded sample of whole 512^2 blocks of the same plane.
 """
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -39,19 +51,54 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PX = {  # 2*9*cin*cout per CNN pixel
-    (1, 32): 576, (32, 32): 18432, (32, 64): 36864, (64, 64): 73728, (64, 128): 147456, (128, 128): 294912, (128, 1): 2304,
-}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_16BIT_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+PRECISIONS = ["fp32", "bf16", "bf16x2", "bf16x3", "fp16x2"]
 
 
-def synth_frame_luma(seed, h=1080, w=1920):
-    """seeded RGB uint8 frame -> Y plane in [0,1] (OpenCV RGB2YUV luma weights) -> nearest 2x"""
+def synth_luma(seed, h, w):
+    """seeded RGB uint8 frame -> Y plane in [0,1] (OpenCV RGB2YUV luma weights), generated in row strips"""
     rng = np.random.default_rng(seed)
-    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8).astype(np.float32) / np.float32(255.0)
-    y = (np.float32(0.299) * rgb[..., 0] + np.float32(0.587) * rgb[..., 1] + np.float32(0.114) * rgb[..., 2]).astype(np.float32)
+    y = np.empty((h, w), np.float32)
+    for r0 in range(0, h, 1024):
+        r1 = min(h, r0 + 1024)
+        rgb = rng.integers(0, 256, size=(r1 - r0, w, 3), dtype=np.uint8).astype(np.float32) / np.float32(255.0)
+        y[r0:r1] = np.float32(0.299) * rgb[..., 0] + np.float32(0.587) * rgb[..., 1] + np.float32(0.114) * rgb[..., 2]
+    return y
+
+
+def nn2x(y):
     return np.repeat(np.repeat(y, 2, axis=0), 2, axis=1)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel + engine sources: a committed PMC profile only describes the code it was taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "waifu2x-converter-cpp_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, cin, cout, H, W):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/make_profile_summary.py).  rocprofv3 cannot
+    run inside this process, so this is the profile of the SAME command -- valid only for the sources it was taken
+    from: returns (bytes, note)."""
+    path = os.path.join(ROOT, "profiles", "r2_roofline.json")
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None, "no committed PMC profile (profiles/r2_roofline.json)"
+    if prof.get("kernel_source_hash") != kernel_source_hash():
+        return None, "committed PMC profile is from other kernel sources (hash %s != %s): dropped" % (prof.get("kernel_source_hash"), kernel_source_hash())
+    for name, k in prof.get("kernels", {}).items():
+        if kernel in name and ("<%d, %d" % (cin, cout)) in name and k.get("pixels") == (H + 2) * (W + 2):
+            return int(k["hbm_traffic_bytes"]), "profiles/r2_roofline.json (rocprofv3 --pmc, same command, same sources)"
+    return None, "no matching kernel in profiles/r2_roofline.json"
 
 
 def cpu_baseline(layers, plane, budget_s=15.0):
@@ -100,45 +147,34 @@ def cpu_baseline(layers, plane, budget_s=15.0):
     return res
 
 
-def pmc_traffic(kernel, cin, cout, H, W):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_roofline.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).
-    rocprofv3 cannot run inside this process, so this is the profile of the SAME command
-    (tools/profile.sh); null when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r1_roofline.json")
-    try:
-        prof = json.load(open(path))
-    except Exception:
-        return None
-    for name, k in prof.get("kernels", {}).items():
-        if kernel in name and ("<%d, %d" % (cin, cout)) in name and k.get("pixels") == (H + 2) * (W + 2):
-            return int(k["hbm_traffic_bytes"])
-    return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--height", type=int, default=1080, help="input frame height (CNN plane is 2x)")
-    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=0, help="input frame height (CNN plane is 2x); default 1080 (plane workload: 8192)")
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-precisions", action="store_true", help="skip the informational opt-in-precision runs after the timed region")
+    ap.add_argument("--no-extras", "--no-other-precisions", dest="no_extras", action="store_true",
+                    help="skip the informational legs after the timed region (other precisions, the 8192x8192 plane at N=1, the weak figure at N>1)")
+    ap.add_argument("--no-host", action="store_true", help="skip the host->host leg")
+    ap.add_argument("--host-steps", type=int, default=0, help="host->host calls to time (default: max(5, steps))")
+    ap.add_argument("--jobs", type=int, default=0, help="modelUtility nJob = host staging threads of the host->host path (default: min(8, cores / ranks))")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x2", "bf16x3", "fp16x2"],
+    ap.add_argument("--precision", default="fp32", choices=PRECISIONS,
                     help="bf16 = W2XC_PRECISION_BF16 (configs[3] arithmetic); bf16x2 / bf16x3 / fp16x2 = split products (fp32 values "
                          "as 2 / 3 bf16 terms or 2 fp16 terms on the 16-bit MFMAs).  NOT the headline number: the reference computes in fp32 "
                          "and `value` is only the BASELINE metric for the default")
-    ap.add_argument("--workload", default="scale2x_1080p", choices=["scale2x_1080p", "plane", "image_u8"],
-                    help="'plane': ONE --width x --height frame whose CNN plane is sharded into row bands over the "
-                         "ranks (BASELINE.json configs[2] with --width 8192 --height 8192): strong scaling")
+    ap.add_argument("--workload", default="auto", choices=["auto", "scale2x_1080p", "plane", "image_u8"],
+                    help="auto = scale2x_1080p at N=1, plane (8192x8192, BASELINE.json configs[2]) at N>1.  'plane': ONE --width x --height "
+                         "frame whose CNN plane is sharded into row ranges over the ranks: strong scaling")
+    ap.add_argument("--dump-out", default="", help="(tests) directory: every rank saves its output rows of the last step as rank<r>.npz")
     args = ap.parse_args()
 
     import torch
     import __graft_entry__ as graft
-    from oracle import gen_model
+    from tools import gen_model
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,42 +201,28 @@ def main():
             dist.init_process_group(backend=backend)
 
     w2xc = graft.load_package()
+    lib = w2xc.lib()
     layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
     ms = w2xc._ModelSet.from_layers(layers)
     n_layers = ms.n_layers
+    njobs = args.jobs if args.jobs > 0 else max(1, min(8, (os.cpu_count() or 4) // world))
+    lib.w2xc_set_jobs(njobs)
 
-    sharded = args.workload == "plane"
-    plane = synth_frame_luma(seed=2 + (0 if sharded else rank), h=args.height, w=args.width)
-    H, W = plane.shape
+    workload = args.workload
+    if workload == "auto":
+        workload = "scale2x_1080p" if world == 1 else "plane"
+    sharded = workload == "plane"
+    in_h = args.height or (8192 if sharded else 1080)
+    in_w = args.width or (8192 if sharded else 1920)
+    H, W = 2 * in_h, 2 * in_w
+    prec_code = {"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2,
+                 "bf16x3": w2xc.PRECISION_BF16X3, "fp16x2": w2xc.PRECISION_FP16X2}
     stream = torch.cuda.current_stream()
-    opts = w2xc.make_opts(device=dev_index, profile=1, band_rows=args.band_rows,
-                          precision={"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2,
-                                     "bf16x3": w2xc.PRECISION_BF16X3, "fp16x2": w2xc.PRECISION_FP16X2}[args.precision])
-    if args.workload == "image_u8":
-        # N2: uint8 RGB frame in HBM -> uint8 2x frame in HBM (colour conversion, bicubic U/V, CNN on Y, back to uint8)
-        rgb = np.random.default_rng(2 + rank).integers(0, 256, size=(args.height, args.width, 3), dtype=np.uint8)
-        d_in = torch.from_numpy(rgb).cuda()
-        d_out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
 
-        def step():
-            ms.scale2x_image_u8_device(d_in.data_ptr(), args.width * 3, args.width, args.height, d_out.data_ptr(), W * 3, 1,
-                                       stream=stream.cuda_stream, opts=opts)
-    elif sharded:
-        # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo) is resident in HBM
-        ra, rb = w2xc.shard_rows(H, world, rank)
-        y0, y1 = w2xc.shard_view(H, ra, rb, n_layers)
-        d_in = torch.from_numpy(np.ascontiguousarray(plane[y0:y1])).cuda()
-        d_out = torch.empty((rb - ra, W), dtype=torch.float32, device="cuda")
-
-        def step():
-            ms.convert_rows_device(d_in.data_ptr(), W * 4, y1 - y0, y0, W, H, ra, rb, d_out.data_ptr(), W * 4,
-                                   stream=stream.cuda_stream, opts=opts)
-    else:
-        d_in = torch.from_numpy(plane).cuda()
-        d_out = torch.empty_like(d_in)
-
-        def step():
-            ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=opts)
+    def mk_opts(profile=0, precision=None, band_rows=None):
+        return w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, profile=profile,
+                              band_rows=args.band_rows if band_rows is None else band_rows,
+                              precision=prec_code[precision or args.precision])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -208,29 +230,195 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    ms.profile_reset(dev_index)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
+    def time_steps(step, steps, warmup):
+        """the bench contract: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks"""
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # ---- the resident workloads: inputs and outputs live in HBM, device-pointer entry points ------------------------
+    def resident_frame(y_src, opts_of):
+        """one whole frame per rank (weak scaling): CNN plane = nearest-2x of y_src, resident"""
+        d_in = torch.from_numpy(nn2x(y_src)).cuda()
+        d_out = torch.empty_like(d_in)
+        h2, w2 = d_in.shape
+
+        def step(opts):
+            ms.convert_device(d_in.data_ptr(), w2 * 4, w2, h2, d_out.data_ptr(), w2 * 4, stream=stream.cuda_stream, opts=opts)
+        return (lambda: step(opts_of(0))), (lambda: step(opts_of(1))), d_in, d_out
+
+    y_src = synth_luma(seed=2 + (0 if sharded else rank), h=in_h, w=in_w)
+    ra, rb = (w2xc.shard_rows(H, world, rank) if sharded else (0, H))
+    if workload == "image_u8":
+        # N2: uint8 RGB frame in HBM -> uint8 2x frame in HBM (colour conversion, bicubic U/V, CNN on Y, back to uint8)
+        rgb = np.random.default_rng(2 + rank).integers(0, 256, size=(in_h, in_w, 3), dtype=np.uint8)
+        d_in = torch.from_numpy(rgb).cuda()
+        d_out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+
+        def mk_step(profile):
+            o = mk_opts(profile)
+            return lambda: ms.scale2x_image_u8_device(d_in.data_ptr(), in_w * 3, in_w, in_h, d_out.data_ptr(), W * 3, 1,
+                                                      stream=stream.cuda_stream, opts=o)
+        step, step_prof = mk_step(0), mk_step(1)
+    elif sharded:
+        # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo of the 2x plane) is resident in HBM
+        y0, y1 = w2xc.shard_view(H, ra, rb, n_layers)
+        view = nn2x(y_src[y0 // 2:(y1 + 1) // 2])[y0 - 2 * (y0 // 2):][:y1 - y0]
+        d_in = torch.from_numpy(np.ascontiguousarray(view)).cuda()
+        del view
+        d_out = torch.empty((rb - ra, W), dtype=torch.float32, device="cuda")
+
+        def mk_step(profile):
+            o = mk_opts(profile)
+            return lambda: ms.convert_rows_device(d_in.data_ptr(), W * 4, y1 - y0, y0, W, H, ra, rb, d_out.data_ptr(), W * 4,
+                                                  stream=stream.cuda_stream, opts=o)
+        step, step_prof = mk_step(0), mk_step(1)
+    else:
+        step, step_prof, d_in, d_out = resident_frame(y_src, lambda p: mk_opts(p))
+
+    elapsed = time_steps(step, args.steps, args.warmup)
+    # second pass, same K steps, with the per-layer hipEvents on the launch stream: per-kernel durations for `roofline`
+    ms.profile_reset(dev_index)
+    sync_all()
+    tp0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_prof()
+    sync_all()
+    elapsed_prof = max_over_ranks(time.perf_counter() - tp0)
     layer_ms, launches = ms.profile_read(dev_index)
     ok = bool(torch.isfinite(d_out.float()).all().item())
+    if args.dump_out:
+        os.makedirs(args.dump_out, exist_ok=True)
+        np.savez(os.path.join(args.dump_out, "rank%d.npz" % rank), ra=ra, rb=rb, rows=d_out.cpu().numpy())
+
+    # ---- host -> host (SURVEY 8d): the convertWithModels call on HOST planes, PCIe and stitch included ----------------
+    host = None
+    if not args.no_host and workload != "image_u8":
+        hsteps = args.host_steps or max(5, min(args.steps, 20))
+
+        def host_leg(precision, pinned, steps):
+            """rows [ra, rb) of the 2x conversion of y_src: host source plane in (nearest-2x fused into layer 1, so the 4x
+            larger plane never crosses PCIe, main.cpp:132-148), host output rows out.  Per-call wall times."""
+            sy0, sy1 = max(0, ra - n_layers) // 2, (min(H, rb + n_layers) + 1) // 2
+            if pinned:
+                src = torch.from_numpy(y_src[sy0:sy1]).pin_memory()
+                dst = torch.empty((rb - ra, W), dtype=torch.float32).pin_memory()
+                src_np, dst_np = src.numpy(), dst.numpy()
+            else:
+                src_np = np.ascontiguousarray(y_src[sy0:sy1])
+                dst_np = np.zeros((rb - ra, W), np.float32)   # touched once: no first-touch page faults inside the timing
+            o = mk_opts(0, precision)
+
+            def call():
+                rc = lib.w2xc_convert_plane_rows(ms.handle, src_np.ctypes.data, src_np.strides[0], sy0, sy1 - sy0, in_w, in_h, 1, ra, rb,
+                                                 dst_np.ctypes.data, dst_np.strides[0], C.byref(o))
+                if rc != 0:
+                    raise RuntimeError("w2xc_convert_plane_rows: " + w2xc.last_error())
+            call()
+            call()
+            times = []
+            for _ in range(steps):
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                call()
+                times.append(max_over_ranks(time.perf_counter() - t0))
+            return times, dst_np
+
+        res_ms = elapsed / args.steps * 1e3
+        px_job = in_h * in_w * (1 if sharded else world)
+        host = {"definition": "SURVEY 8(d): wall time of the convertWithModels-equivalent call, HOST luma plane in -> HOST 2x plane out "
+                              "(w2xc_convert_plane_rows, nearest-2x fused, pinned staging rings, H2D / layers / D2H+stitch overlapped), "
+                              "median of %d calls, nJob=%d staging threads" % (hsteps, njobs)}
+        for label, pinned in (("pageable", False), ("pinned", True)):
+            times, dst_np = host_leg(args.precision, pinned, hsteps)
+            med = statistics.median(times) * 1e3
+            host[label] = {"ms_median": round(med, 4), "ms_min": round(min(times) * 1e3, 4), "Mpix_s": round(px_job / med / 1e3, 4),
+                           "ratio_vs_resident": round(res_ms / med, 4)}
+            if label == "pageable":
+                dev_rows = d_out.cpu().numpy()
+                host["max_abs_diff_vs_resident_output"] = float(np.abs(dst_np - dev_rows).max())
+        if world == 1 and not args.no_extras and args.precision == "fp32":
+            t_res = time_steps(lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream,
+                                                         opts=mk_opts(0, "fp16x2")), 5, 2) / 5 * 1e3
+            times, _ = host_leg("fp16x2", False, hsteps)
+            med = statistics.median(times) * 1e3
+            host["fp16x2_pageable"] = {"ms_median": round(med, 4), "resident_ms": round(t_res, 4), "ratio_vs_resident": round(t_res / med, 4)}
+
+    # ---- informational legs --------------------------------------------------------------------------------------------
+    extras = {}
+    if not args.no_extras and args.precision == "fp32" and workload != "image_u8":
+        try:
+            if world == 1 and workload == "scale2x_1080p":
+                # the opt-in precisions on the same resident plane (3 steps each): their time and their distance from the
+                # fp32 result just measured.  Informational -- `value` above is fp32.
+                other = {}
+                step()
+                torch.cuda.synchronize()
+                ref = d_out.clone()
+                rng = float(ref.abs().max().item())
+                for name in ("fp16x2", "bf16x3", "bf16x2", "bf16"):
+                    o2 = mk_opts(0, name)
+                    run = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o2)
+                    t = time_steps(run, 3, 1) / 3 * 1e3
+                    other[name] = {"ms_per_step": round(t, 3), "Mpix_s": round(in_h * in_w / t / 1e3, 2),
+                                   "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
+                extras["other_precisions"] = other
+                # BASELINE.json configs[2] on ONE GPU (what N > 1 shards): 8192x8192 frame, host -> host and resident
+                del ref
+                yb = synth_luma(seed=2, h=8192, w=8192)
+                o3 = mk_opts(0)
+                outb = np.zeros((16384, 16384), np.float32)
+
+                def call_big():
+                    rc = lib.w2xc_convert_plane_nn2x(ms.handle, yb.ctypes.data, yb.strides[0], 8192, 8192, outb.ctypes.data, outb.strides[0], C.byref(o3))
+                    if rc != 0:
+                        raise RuntimeError(w2xc.last_error())
+                call_big()
+                tb = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    call_big()
+                    tb.append(time.perf_counter() - t0)
+                d_yb = torch.from_numpy(yb).cuda()
+                d_ob = torch.empty((16384, 16384), dtype=torch.float32, device="cuda")
+                run = lambda: ms.convert_nn2x_device(d_yb.data_ptr(), 8192 * 4, 8192, 8192, d_ob.data_ptr(), 16384 * 4, stream=stream.cuda_stream, opts=o3)
+                tr = time_steps(run, 2, 1) / 2
+                extras["plane_8192"] = {"workload": "BASELINE.json configs[2] on one GPU: 8192x8192 frame -> 16384x16384 CNN plane, workspace-banded",
+                                        "resident_ms": round(tr * 1e3, 2), "resident_Mpix_s": round(8192 * 8192 / tr / 1e6, 3),
+                                        "host_to_host_ms_median": round(statistics.median(tb) * 1e3, 2),
+                                        "host_to_host_Mpix_s": round(8192 * 8192 / statistics.median(tb) / 1e6, 3),
+                                        "host_output_finite": bool(np.isfinite(outb[::97, ::89]).all())}
+                del d_yb, d_ob, outb, yb
+            elif world > 1 and sharded:
+                # weak scaling beside the strong-scaling headline: every rank converts its own 1080p frame
+                yw = synth_luma(seed=2 + rank, h=1080, w=1920)
+                stepw, _, dw_in, dw_out = resident_frame(yw, lambda p: mk_opts(p, band_rows=0))
+                tw = time_steps(stepw, args.steps, args.warmup)
+                extras["weak"] = {"workload": "scale2x_1080p: one 1920x1080 frame per rank per step (BASELINE.json configs[1] x N)",
+                                  "value": round(world * 1080 * 1920 * args.steps / tw / 1e6, 4), "unit": "Mpix/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
+                                  "scaling": "weak"}
+        except Exception as e:   # never let a side measurement break the headline line
+            extras["extras_error"] = repr(e)
 
     if rank == 0:
-        in_px = args.height * args.width
+        in_px = in_h * in_w
         value = (1 if sharded else world) * in_px * args.steps / elapsed / 1e6
         # algorithmic FLOPs of one step per layer: every band launch of layer k computes
         # (band rows + 2(n-k)) x (W + 2(n-k)) pixels (valid conv on the haloed band)
-        band_h = (rb - ra) if sharded else H
+        band_h = rb - ra
         flops_layer, nbands = [], []
         for l in range(n_layers):
             cin, cout = ms.planes(l)
@@ -244,16 +432,25 @@ def main():
         dom_ms = layer_ms[dom] / dom_launches
         bands = nbands[dom]
         dom_flops = flops_layer[dom] / bands
+        opts = mk_opts(0)
         # split modes: every algorithmic multiply-add is 3 (bf16x2, fp16x2) or 6 (bf16x3) 16-bit MFMA products
         products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "fp16x2": 3}[args.precision]
+        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
         achieved = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         per_layer = []
         for l in range(n_layers):
             ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
             cin, cout = ms.planes(l)
+            alg_bytes = (cin + cout) * 4 * flops_layer[l] / (18 * cin * cout)
             per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l, opts), "planes": "%d->%d" % (cin, cout),
                               "ms": round(ms_l, 4),
-                              "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None})
+                              "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None,
+                              "frac_of_peak": round(products * flops_layer[l] / (ms_l * 1e-3) / 1e12 / peak, 4) if ms_l > 0 else None,
+                              "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
+        traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
+                                 if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else (None, "no PMC profile for this configuration"))
+        wl_name = {"scale2x_1080p": "scale2x_1080p (BASELINE.json configs[1])", "plane": "plane, row-sharded over ranks (BASELINE.json configs[2] at 8192x8192)",
+                   "image_u8": "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU)"}[workload]
         out = {
             "metric": "Mpixels/sec end-to-end scale2.0x 7-layer conv",
             "value": round(value, 4),
@@ -267,47 +464,35 @@ def main():
                       "fp16x2": "f32 values as 2 fp16 terms (3 fp16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision",
                       "bf16x3": "f32 values as 3 bf16 terms (6 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": ("plane (row-band sharded over ranks): " if sharded else "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU): " if args.workload == "image_u8" else "scale2x_1080p: ") + "scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
-                                   "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, one frame per GPU per step, "
-                                   "planes resident in HBM" % (args.width, args.height, W, H),
-                       "cnn_plane": [H, W], "frames_per_step": 1 if sharded else world, "bands_per_frame": max(bands, 1),
-                       "sharding": "independent frames per rank, no collective on the data path"},
+            "value_is": "planes resident in HBM when the timed region starts (bench contract); the PCIe-inclusive host->host figure is `host_to_host`",
+            "value_resident": round(value, 4),
+            "value_host_to_host": host["pageable"]["Mpix_s"] if host else None,
+            "config": {"workload": wl_name + ": scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
+                                   "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, %s" %
+                                   (in_w, in_h, W, H, ("ONE frame per step, rank r computes rows [H*r/N, H*(r+1)/N) (+7-row halo), no exchange" if sharded
+                                                       else "one frame per GPU per step")),
+                       "cnn_plane": [H, W], "frames_per_step": 1 if sharded else world, "bands_per_unit": max(bands, 1),
+                       "sharding": ("contiguous row ranges of one plane per rank, no collective on the data path, host-side gather" if sharded
+                                    else "independent frames per rank, no collective on the data path")},
+            "ms_per_step_profiled": round(elapsed_prof / args.steps * 1e3, 4),
             "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom, opts), dom + 1) + ms.planes(dom)),
-                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else 2500.0), 4),
-                         "traffic": pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
-                         if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else None,
+                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
-                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops, "mfma_products_per_fma": products},
+                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops, "mfma_products_per_fma": products,
+                         "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,
             "output_finite": ok,
         }
-        if world == 1 and args.precision == "fp32" and args.workload == "scale2x_1080p" and not args.no_other_precisions:
-            # the opt-in precisions on the same resident plane, right after the timed region (3 steps each): their
-            # time and their distance from the fp32 result just measured.  Informational -- `value` above is fp32.
-            try:
-                other = {}
-                ref = d_out.clone()
-                rng = float(ref.abs().max().item())
-                for name, prec in (("fp16x2", w2xc.PRECISION_FP16X2), ("bf16x3", w2xc.PRECISION_BF16X3),
-                                   ("bf16x2", w2xc.PRECISION_BF16X2), ("bf16", w2xc.PRECISION_BF16)):
-                    o2 = w2xc.make_opts(device=dev_index, band_rows=args.band_rows, precision=prec)
-                    run = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o2)
-                    run()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        run()
-                    torch.cuda.synchronize()
-                    ms_p = (time.perf_counter() - t1) / 3 * 1e3
-                    other[name] = {"ms_per_step": round(ms_p, 3), "Mpix_s": round(in_px / ms_p / 1e3, 2),
-                                   "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
-                out["other_precisions"] = other
-            except Exception as e:   # never let the side measurement break the headline line
-                out["other_precisions"] = {"error": str(e)}
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(layers, plane, args.cpu_budget)
-            out["speedup_vs_cpu"] = round(value / world / out["cpu_baseline"]["value"], 1)
+        if host:
+            out["host_to_host"] = host
+        out.update(extras)
+        if not args.no_cpu_baseline and world == 1 and workload != "image_u8":   # rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(layers, nn2x(y_src), args.cpu_budget)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            if host:
+                out["speedup_vs_cpu_host_to_host"] = round(host["pageable"]["Mpix_s"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -14,8 +14,11 @@
  * Differences from the reference, by design:
  *   - nothing in here calls std::exit: constructor / filter failures surface as `false` from the
  *     calling API (a failed Model constructor leaves an invalid model whose filter() fails);
- *   - setNumberOfJobs() is accepted and stored but does not size a CPU thread pool -- the layer
- *     runs on the GPU(s); the block size likewise does not change results.
+ *   - setNumberOfJobs() sizes the HOST STAGING threads (the copies between the caller's planes and the pinned rings
+ *     that feed the DMA engines) instead of a pool of convolution threads -- the layer runs on the GPU(s); the block
+ *     size does not change results and is not used for tiling;
+ *   - Model::filter called in a chain (test.cpp:72-85) re-uploads its input planes on every call unless the process
+ *     sets W2XC_FILTER_RESIDENT=1, which promises that planes handed back unchanged may be taken from the device copy.
  */
 #ifndef W2XC_HIP_MODEL_HANDLER_HPP_
 #define W2XC_HIP_MODEL_HANDLER_HPP_
@@ -70,33 +73,51 @@ private:
 
 public:
 #ifdef W2XC_HIP_HAVE_PICOJSON
-    /* modelHandler.hpp:48-71 + modelHandler.cpp:74-115: one layer from its JSON object */
+    /* One layer from its JSON object (the contract of modelHandler.hpp:48-71 + modelHandler.cpp:74-115: weight[o][i][kh][kw]
+     * doubles narrowed to float, kernel index o * nInputPlanes + i, biases kept as doubles).  Flat, bounds-checked walk:
+     * a malformed object yields an INVALID model (filter() returns false) instead of the reference's exit(-1) / UB. */
     Model(picojson::object &jsonObj)
     {
-        nInputPlanes = static_cast<int>(jsonObj["nInputPlane"].get<double>());
-        nOutputPlanes = static_cast<int>(jsonObj["nOutputPlane"].get<double>());
-        const int kernelSize = static_cast<int>(jsonObj["kW"].get<double>());
-        if (kernelSize != static_cast<int>(jsonObj["kH"].get<double>()) || kernelSize != 3) {
-            std::cerr << "Error : Model-Constructor : \n"
-                         "kernel in model is not square (or not 3x3).\n" << std::endl;
+        auto number = [&](const char *key, double &v) {
+            auto it = jsonObj.find(key);
+            if (it == jsonObj.end() || !it->second.is<double>()) return false;
+            v = it->second.get<double>();
+            return true;
+        };
+        double nin = 0, nout = 0, kw = 0, kh = 0;
+        if (!number("nInputPlane", nin) || !number("nOutputPlane", nout) || !number("kW", kw) || !number("kH", kh) ||
+            !(nin >= 1 && nin <= 4096 && nout >= 1 && nout <= 4096)) {
+            std::cerr << "Error : Model-Constructor : \nbad layer object." << std::endl;
+            return;
+        }
+        nInputPlanes = static_cast<int>(nin);
+        nOutputPlanes = static_cast<int>(nout);
+        if (static_cast<int>(kw) != static_cast<int>(kh) || static_cast<int>(kw) != 3) {
+            std::cerr << "Error : Model-Constructor : \nkernel in model is not square (or not 3x3).\n" << std::endl;
             return;   /* invalid model: filter() will fail (the reference exit(-1)s here) */
         }
-        std::vector<float> w((size_t)nInputPlanes * nOutputPlanes * 9);
-        std::vector<double> b(nOutputPlanes);
-        picojson::array &wOutputPlane = jsonObj["weight"].get<picojson::array>();
-        size_t k = 0;
-        for (auto &&wInputPlaneV : wOutputPlane)
-            for (auto &&weightMatV : wInputPlaneV.get<picojson::array>()) {
-                picojson::array &weightMat = weightMatV.get<picojson::array>();
-                for (int r = 0; r < 3; r++) {
-                    picojson::array &row = weightMat.at(r).get<picojson::array>();
-                    for (int c = 0; c < 3; c++) w.at(k++) = static_cast<float>(row[c].get<double>());
-                }
+        auto wit = jsonObj.find("weight"), bit = jsonObj.find("bias");
+        if (wit == jsonObj.end() || bit == jsonObj.end() || !wit->second.is<picojson::array>() || !bit->second.is<picojson::array>()) return;
+        const picojson::array &W = wit->second.get<picojson::array>(), &B = bit->second.get<picojson::array>();
+        if ((int)W.size() != nOutputPlanes || (int)B.size() < nOutputPlanes) return;
+        std::vector<float> taps((size_t)nInputPlanes * nOutputPlanes * 9);
+        std::vector<double> bias(nOutputPlanes);
+        for (size_t k = 0; k < taps.size(); k++) {          /* k = ((o * nIn + i) * 3 + r) * 3 + c */
+            const size_t c = k % 3, r = (k / 3) % 3, i = (k / 9) % (size_t)nInputPlanes, o = k / (9 * (size_t)nInputPlanes);
+            const picojson::value *v = &W[o];
+            for (size_t idx : {i, r, c}) {
+                if (!v->is<picojson::array>() || v->get<picojson::array>().size() <= idx) return;
+                v = &v->get<picojson::array>()[idx];
             }
-        picojson::array &biasesData = jsonObj["bias"].get<picojson::array>();
-        for (int i = 0; i < nOutputPlanes; i++) b[i] = biasesData[i].get<double>();
-        const float *wp = w.data();
-        const double *bp = b.data();
+            if (!v->is<double>()) return;
+            taps[k] = static_cast<float>(v->get<double>());
+        }
+        for (int o = 0; o < nOutputPlanes; o++) {
+            if (!B[o].is<double>()) return;
+            bias[o] = B[o].get<double>();
+        }
+        const float *wp = taps.data();
+        const double *bp = bias.data();
         w2xc_model *m = nullptr;
         if (w2xc_model_from_arrays(1, &nInputPlanes, &nOutputPlanes, &wp, &bp, &m) == W2XC_OK)
             set = std::make_shared<detail::ModelHandle>(m);

@@ -67,6 +67,11 @@ typedef struct w2xc_opts {
     int      workspace_mb;    /* activation workspace budget per device in MiB; 0 = default (16384) */
     int      profile;         /* 1 = bracket every layer launch with hipEvents (see below)          */
     int      verbose;         /* 1 = print the reference's progress lines (convertRoutine.cpp:67)   */
+    int      filter_resident; /* w2xc_layer_filter: 1 = when the input planes are exactly the planes the previous
+                               * w2xc_layer_filter call on this model wrote (same pointers, count, size) the caller
+                               * promises they are unmodified, and the copy still on the device is used instead of
+                               * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
+                               * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
 } w2xc_opts;
 
 /* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding). */
@@ -109,7 +114,13 @@ void w2xc_get_block_size(int *w, int *h);     /* default 512x512 (hpp:99)       
  * (:84-169), so `block_splitting` and the singleton block size do not change results and the
  * engine bands the plane by its own workspace budget.  No clipping (Q2).  Uses every device in
  * opts->device_mask: row bands are striped over devices, one host thread per device, no
- * inter-device traffic.  opts may be NULL. */
+ * inter-device traffic.  opts may be NULL.
+ * Host pipeline (per model and device, created once and kept): three HIP streams (H2D, layers, D2H), device copies of
+ * this device's rows, and rings of pinned staging slots.  The caller's pageable planes are copied into / out of the
+ * slots by modelUtility's nJob host threads (w2xc_set_jobs) while the DMA engines and the kernels run: the upload of
+ * band k+1 and the download + stitch of the previous rows overlap the layers of band k; the last layer is launched in
+ * ~2 MiB row chunks so its rows leave while the rest is still computed.  Planes that are already page-locked
+ * (hipHostMalloc / hipHostRegister) are DMA'd in place.  The call returns when `out` is complete. */
 int w2xc_convert_plane(w2xc_model *m, const float *in, size_t in_stride_bytes, int w, int h,
                        float *out, size_t out_stride_bytes, int block_splitting,
                        const w2xc_opts *opts);
@@ -152,6 +163,16 @@ int w2xc_convert_plane_nn2x(w2xc_model *m, const float *in, size_t in_stride_byt
 int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h,
                                    float *d_out, size_t out_stride_bytes, void *hip_stream,
                                    const w2xc_opts *opts);
+
+/* One UNIT of the tile farm from host memory (the reference's block walk, convertRoutine.cpp:114-165, made parallel across
+ * processes): output rows [row_begin, row_end) of the conversion of a w x h source plane (nn2x = 1: of its nearest-
+ * neighbour 2x, main.cpp:132-140, so the output plane is 2w x 2h and row numbers are in OUTPUT coordinates).
+ * `in_view` points at source row view_y0 and holds view_h rows, which must cover every source row the range reads
+ * (rows [row_begin - n_layers, row_end + n_layers) of the plane, halved for nn2x, clipped); `out` points at output row
+ * row_begin.  Same pinned-staged, overlapped pipeline and device_mask semantics as w2xc_convert_plane; units never
+ * exchange data, so N processes each calling this with their own row range ARE the multi-GPU farm (host-side gather only). */
+int w2xc_convert_plane_rows(w2xc_model *m, const float *in_view, size_t in_stride_bytes, int view_y0, int view_h, int w, int h,
+                            int nn2x, int row_begin, int row_end, float *out, size_t out_stride_bytes, const w2xc_opts *opts);
 
 /* N2: the whole SCALE PHASE of the CLI for one image, device-resident:
  *   convertTo(CV_32F, 1/255) + cvtColor(COLOR_RGB2YUV) on the three channels as given  (main.cpp:75-76)
@@ -198,6 +219,15 @@ int w2xc_yuv_to_u8_device(const float *d_y, const float *d_u, const float *d_v, 
 int w2xc_layer_filter(w2xc_model *m, int layer, int n_in_planes, const float *const *in_planes,
                       size_t in_stride_bytes, int w, int h, float *const *out_planes,
                       size_t out_stride_bytes, const w2xc_opts *opts);
+
+/* The same layer on DEVICE data with arbitrary element strides (in floats): element (plane c, row y, pixel x) is at
+ * base[c*plane_stride + y*row_stride + x*pixel_stride] -- planar planes (pixel_stride 1) as Model::filter has them, or
+ * NHWC (plane_stride 1, pixel_stride = plane count, 16-byte aligned), which the MFMA kernels use directly so a chain
+ * of calls that hands NHWC from layer to layer never repacks.  Asynchronous on `hip_stream`. */
+int w2xc_layer_filter_device(w2xc_model *m, int layer, int n_in_planes, const float *d_in, long long in_plane_stride,
+                             long long in_row_stride, long long in_pixel_stride, int w, int h, float *d_out,
+                             long long out_plane_stride, long long out_row_stride, long long out_pixel_stride,
+                             void *hip_stream, const w2xc_opts *opts);
 
 /* ---- measurement / introspection ------------------------------------------------------------ */
 

@@ -9,7 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import __graft_entry__ as graft  # noqa: E402
-from oracle import gen_model, oracle as orc  # noqa: E402  (tests may use the checker)
+from tools import gen_model
+from oracle import oracle as orc  # noqa: E402  (tests may use the checker)
 
 
 def pytest_configure(config):

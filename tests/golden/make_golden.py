@@ -2,7 +2,7 @@
 modelHandler.cpp + convertRoutine.cpp over the OpenCV shim).  Run in the build container, where
 /root/reference exists:  python tests/golden/make_golden.py
 
-Each fixture: planes (topology), seed (oracle/gen_model.synth_layers), block (singleton block size),
+Each fixture: planes (topology), seed (tools/gen_model.synth_layers), block (singleton block size),
 input plane, and the reference's convertWithModels output.  Small on purpose (<100 KB each)."""
 import os
 import sys
@@ -12,7 +12,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from oracle import gen_model, oracle as orc  # noqa: E402
+from tools import gen_model
+from oracle import oracle as orc  # noqa: E402
 
 CASES = [
     # name, planes, seed, (h, w), block

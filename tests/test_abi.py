@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, rand_plane, small_layers
-from oracle import gen_model, oracle as orc
+from tools import gen_model
+from oracle import oracle as orc
 
 
 def header_functions():
@@ -123,6 +124,57 @@ def test_opts_defaults(w2xc):
     assert (o.precision, o.kernel, o.device, o.device_mask, o.band_rows, o.profile) == (0, 0, -1, 0, 0, 0)
 
 
+def test_opts_struct_size_versions_the_abi(w2xc, noise1_layers):
+    """a caller compiled against an OLDER (shorter) w2xc_opts passes its own struct_size: only that prefix is read, the
+    newer fields take their defaults; a LARGER struct_size (newer caller, older library) reads only what the library knows"""
+    ms = w2xc._ModelSet.from_layers(noise1_layers)
+    lib = w2xc.lib()
+
+    class OldOpts(C.Structure):      # the first three fields only: struct_size, precision, kernel
+        _fields_ = [("struct_size", C.c_int), ("precision", C.c_int), ("kernel", C.c_int)]
+    name = lib.w2xc_layer_kernel_name
+    old = OldOpts(C.sizeof(OldOpts), w2xc.PRECISION_FP32, w2xc.KERNEL_DIRECT)
+    # place the short struct at the END of a buffer whose following bytes are garbage: they must not be read as fields
+    buf = (C.c_char * 64)(*([b"\xff"] * 64))
+    C.memmove(buf, C.byref(old), C.sizeof(old))
+    assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == b"conv3x3_direct"
+    old.kernel = w2xc.KERNEL_AUTO
+    C.memmove(buf, C.byref(old), C.sizeof(old))
+    assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == b"conv3x3_mfma"
+    # precision travels in the prefix too: a 16-bit mode picks the split kernels
+    old.precision = w2xc.PRECISION_FP16X2
+    C.memmove(buf, C.byref(old), C.sizeof(old))
+    assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == b"conv3x3_split"
+    # a newer, larger struct: the library copies sizeof(its own w2xc_opts) and ignores the tail
+    class NewOpts(C.Structure):
+        _fields_ = w2xc.Opts._fields_ + [("future_a", C.c_int), ("future_b", C.c_double)]
+    new = NewOpts()
+    lib.w2xc_opts_init(C.cast(C.byref(new), C.POINTER(w2xc.Opts)))
+    new.struct_size = C.sizeof(NewOpts)
+    new.kernel = w2xc.KERNEL_DIRECT
+    new.future_a = -1
+    assert name(ms.handle, 0, C.cast(C.byref(new), C.POINTER(w2xc.Opts))) == b"conv3x3_direct"
+    o = w2xc.make_opts()
+    assert o.filter_resident == 0 and o.struct_size == C.sizeof(w2xc.Opts) == 40
+
+
+def test_hostile_model_files_do_not_cross_the_abi(w2xc, tmp_path):
+    """huge / non-finite plane counts and truncated files come back as error codes, never as exceptions or UB"""
+    cases = {
+        "huge": '[{"nInputPlane":1e300,"nOutputPlane":1,"kW":3,"kH":3,"bias":[0],"weight":[[[[0,0,0],[0,0,0],[0,0,0]]]]}]',
+        "big": '[{"nInputPlane":2000000000,"nOutputPlane":2000000000,"kW":3,"kH":3,"bias":[0],"weight":[[[[0,0,0],[0,0,0],[0,0,0]]]]}]',
+        "neg": '[{"nInputPlane":-4,"nOutputPlane":1,"kW":3,"kH":3,"bias":[0],"weight":[]}]',
+        "many": '[{"nInputPlane":5000,"nOutputPlane":5000,"kW":3,"kH":3,"bias":[0],"weight":[[[[0,0,0],[0,0,0],[0,0,0]]]]}]',
+        "trunc": '[{"nInputPlane":1,"nOutputPlane":1,"kW":3,"kH":3,"bias":[0],"weight":[[[[0,0,0],[0,0',
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".json")
+        p.write_text(text)
+        with pytest.raises(w2xc.W2xcError) as e:
+            w2xc._ModelSet.from_json(str(p))
+        assert e.value.code == w2xc.ERR_JSON, name
+
+
 def test_argument_validation(w2xc, noise1_layers):
     ms = w2xc._ModelSet.from_layers(noise1_layers)
     lib = w2xc.lib()
@@ -178,6 +230,8 @@ def test_cli_shell_logic():
     assert cli.plan_scale(1.5) == (1, 0.75)
     assert cli.plan_scale(3.0) == (2, 0.75)
     assert cli.plan_scale(2.5) == (2, 0.625)
+    assert cli.plan_scale(0.5) == (0, 0.0)      # iter -1, shrink 0.5 / 2^-1 = 1.0: same-size linear resize = identity (main.cpp:107-114)
+    assert cli.plan_scale(0.3) == (0, 0.6)      # iter -1: the reference shrinks by 0.6, not 0.3
     assert cli.auto_output_name("/x/pic.v1.jpg", "noise_scale", 2, 2.0) == "/x/pic.v1(noise_scale)(Level2)(x2.000000).png"
     assert cli.auto_output_name("a.png", "scale", 1, 1.5) == "a(scale)(x1.500000).png"
     assert cli.auto_output_name("a.png", "noise", 1, 2.0) == "a(noise)(Level1).png"

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, assert_close, rand_plane
-from oracle import gen_model, oracle as orc
+from tools import gen_model
+from oracle import oracle as orc
 
 CPP = os.path.join(ROOT, "tests", "cpp")
 REF_BIN = os.path.join(CPP, "_build", "dropin_ref")

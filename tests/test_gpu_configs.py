@@ -1,0 +1,203 @@
+"""GPU parity at BASELINE.json's FULL sizes (run with -m gpu on an MI355X): every config the metric names, through the
+C ABI, against the oracle.
+
+  configs[1]  2160x3840 CNN plane: the MFMA path against conv3x3_direct on the WHOLE plane (direct is bit-exact against the
+              oracle, pinned here on 40 seeded patches incl. every XCD-chunk boundary of the persistent schedule, every
+              plane border and the band seams), so no tile can hide between patches
+  configs[2]  8192x8192 frame -> 16384x16384 CNN plane, host -> host, workspace-banded; patches at every band seam
+  configs[3]  noise2 -> nearest 2x -> scale2.0x cascade on 4096x4096, bf16 MFMA path, STATED tolerance vs the CPU fp32 cascade
+  configs[4]  3->128->...->3 on three 2048x2048 planes
+plus the weight statistics the synthetic He-init models do not have: the init the real models were trained from
+(srcnn.lua:5-9) and a trained-model-like 10^3 dynamic range with exact zeros, through fp32 AND FP16X2."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, rand_plane
+from tools import gen_model
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances of the 16-bit paths (not the reference's arithmetic): stated here, checked below.
+BF16_MAX_ABS = 2e-2        # max |gpu - cpu fp32| on planes in [0, 1]
+BF16_PSNR_DB = 45.0
+FP16X2_REL_RANGE = 2e-5    # max |gpu - cpu fp32| / max |cpu fp32|
+
+
+@pytest.fixture(scope="module")
+def gpu(w2xc):
+    assert w2xc.device_count() >= 1, "no HIP device visible: libw2xc_hip has no CPU fallback"
+    return w2xc
+
+
+def psnr(a, b, peak=1.0):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 10 * np.log10(peak * peak / max(mse, 1e-30))
+
+
+def oracle_patch(o, plane, y, x, ph, pw, n=7):
+    """rows [y, y+ph) x cols [x, x+pw) of convertWithModels(plane) from a crop with an n-px margin: a crop edge that is a
+    plane border keeps replicate semantics, interior crop edges are discarded -- the reference's own block-split argument
+    (convertRoutine.cpp:84-169)"""
+    H, W = plane.shape
+    y0, y1, x0, x1 = max(0, y - n), min(H, y + ph + n), max(0, x - n), min(W, x + pw + n)
+    sub = o.convert(np.ascontiguousarray(plane[y0:y1, x0:x1]), block_splitting=False, njob=8)
+    return sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw]
+
+
+def test_cfg2_whole_plane_mfma_vs_direct_vs_oracle(gpu, scale_layers):
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    small = np.random.default_rng(2).random((1080, 1920), dtype=np.float32)
+    plane = np.repeat(np.repeat(small, 2, axis=0), 2, axis=1)
+    H, W = plane.shape
+    mfma = ms.convert_nn2x(small)
+    direct = ms.convert_nn2x(small, opts=gpu.make_opts(kernel=gpu.KERNEL_DIRECT))
+    assert mfma.shape == direct.shape == (H, W)
+    # (1) every pixel of the plane: MFMA path vs the reference-ordered kernel
+    assert_close(mfma, direct, "whole 2160x3840 plane, MFMA vs direct")
+    # (2) the reference-ordered kernel is the oracle, bit for bit, wherever we look
+    o = orc.Oracle(scale_layers)
+    spots = [(0, 0), (0, W - 48), (H - 48, 0), (H - 48, W - 48), (0, 1900), (H - 48, 1900), (1056, 0), (1056, W - 48)]
+    # XCD-chunk boundaries of layer 6's persistent schedule: tile list row-major, 8 rows x 32 px, cut in 8 contiguous chunks
+    tiles_x, tiles_y = (W + 2 + 31) // 32, (H + 2 + 7) // 8
+    ntiles = tiles_x * tiles_y
+    for k in range(1, 8):
+        t = k * ntiles // 8
+        ty, tx = divmod(t, tiles_x)
+        spots.append((min(max(ty * 8 - 24, 0), H - 48), min(max(tx * 32 - 24, 0), W - 48)))
+    rng = np.random.default_rng(20)
+    while len(spots) < 40:
+        spots.append((int(rng.integers(0, H - 48)), int(rng.integers(0, W - 48))))
+    for (y, x) in spots:
+        want = oracle_patch(o, plane, y, x, 48, 48)
+        assert np.array_equal(direct[y:y + 48, x:x + 48], want), "direct != oracle at (%d,%d)" % (y, x)
+        assert_close(mfma[y:y + 48, x:x + 48], want, "patch (%d,%d)" % (y, x))
+    # (3) band seams: any banding gives the same plane
+    assert np.array_equal(ms.convert(plane, opts=gpu.make_opts(band_rows=500)), mfma)
+
+
+def test_cfg3_8192_frame_host_to_host(gpu, scale_layers):
+    """BASELINE.json configs[2] on one GPU: w2xc_convert_plane_nn2x on an 8192x8192 luma plane (16384^2 CNN plane, 13
+    workspace bands, staged through the pinned rings)"""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    rng = np.random.default_rng(3)
+    small = np.empty((8192, 8192), np.float32)
+    for r in range(0, 8192, 1024):
+        small[r:r + 1024] = rng.integers(0, 256, size=(1024, 8192), dtype=np.uint8).astype(np.float32) / np.float32(255)
+    got = ms.convert_nn2x(small)
+    H = W = 16384
+    assert got.shape == (H, W)
+    assert np.isfinite(got[::61, ::67]).all()
+    o = orc.Oracle(scale_layers)
+    # band seams of the default budget (16 GiB -> 13 equalised bands of 1261 rows), corners, edges, interior
+    ys = sorted({0, H - 40} | {min(H - 40, max(0, k * 1261 - 20)) for k in range(1, 13)} | {8000})
+    xs = [0, 5000, 9001, W - 40]
+    for i, y in enumerate(ys):
+        x = xs[i % len(xs)]
+        ys0, xs0 = max(0, y - 8) // 2, max(0, x - 8) // 2           # source crop covering the patch + margin
+        ys1, xs1 = min(8192, (y + 40 + 8 + 1) // 2 + 1), min(8192, (x + 40 + 8 + 1) // 2 + 1)
+        up = np.repeat(np.repeat(small[ys0:ys1, xs0:xs1], 2, 0), 2, 1)
+        # `up` starts at plane row 2*ys0: interior crop edges are >= 7 px away from the patch, plane borders coincide
+        assert (ys0 == 0 or y - 2 * ys0 >= 7) and (xs0 == 0 or x - 2 * xs0 >= 7)
+        want = oracle_patch(o, up, y - 2 * ys0, x - 2 * xs0, 40, 40)
+        assert_close(got[y:y + 40, x:x + 40], want, "cfg3 patch (%d,%d)" % (y, x))
+
+
+def cascade_cpu_patch(noise_layers, scale_layers, y_plane, y, x, size):
+    """CPU fp32 cascade (noise model -> nearest 2x -> scale model) for output rows/cols [2y, 2y+2size) of the 2x plane"""
+    m = 12                                                           # 7 (noise) + ceil(7 / 2) (scale, in source pixels) + 1
+    H, W = y_plane.shape
+    y0, y1, x0, x1 = max(0, y - m), min(H, y + size + m), max(0, x - m), min(W, x + size + m)
+    n1 = orc.Oracle(noise_layers).convert(np.ascontiguousarray(y_plane[y0:y1, x0:x1]), block_splitting=False, njob=8)
+    # rows of n1 within 7 of an INTERIOR crop edge are contaminated: drop them (plane borders are exact)
+    t, l = (7 if y0 > 0 else 0), (7 if x0 > 0 else 0)
+    b, r = (7 if y1 < H else 0), (7 if x1 < W else 0)
+    n1 = n1[t:n1.shape[0] - b, l:n1.shape[1] - r]
+    oy, ox = y0 + t, x0 + l
+    s1 = orc.Oracle(scale_layers).convert(np.repeat(np.repeat(n1, 2, 0), 2, 1), block_splitting=False, njob=8)
+    return s1[2 * (y - oy):2 * (y - oy) + 2 * size, 2 * (x - ox):2 * (x - ox) + 2 * size]
+
+
+def test_cfg4_bf16_cascade_4096(gpu, scale_layers):
+    """BASELINE.json configs[3]: noise2 + scale2.0x cascaded on a 4096x4096 luma plane on the bf16 MFMA path (fp32
+    accumulate), tolerance check vs the CPU fp32 cascade; FP16X2 and fp32 through the same cascade for scale"""
+    import torch
+    noise_layers = gen_model.synth_layers(seed=gen_model.SEEDS["noise2"])
+    mn, msc = gpu._ModelSet.from_layers(noise_layers), gpu._ModelSet.from_layers(scale_layers)
+    y = np.random.default_rng(4).random((4096, 4096), dtype=np.float32)
+    d_y = torch.from_numpy(y).cuda()
+    d_n = torch.empty_like(d_y)
+    d_s = torch.empty((8192, 8192), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    spots = [(0, 0), (1000, 1000), (4096 - 72, 4096 - 72), (0, 3000), (2047, 2047), (4096 - 72, 17)]
+    wants = [cascade_cpu_patch(noise_layers, scale_layers, y, yy, xx, 72) for (yy, xx) in spots]
+    report = {}
+    for name, prec in (("bf16", gpu.PRECISION_BF16), ("fp16x2", gpu.PRECISION_FP16X2), ("fp32", gpu.PRECISION_FP32)):
+        o = gpu.make_opts(device=0, precision=prec)
+        mn.convert_device(d_y.data_ptr(), 4096 * 4, 4096, 4096, d_n.data_ptr(), 4096 * 4, stream=st.cuda_stream, opts=o)
+        msc.convert_nn2x_device(d_n.data_ptr(), 4096 * 4, 4096, 4096, d_s.data_ptr(), 8192 * 4, stream=st.cuda_stream, opts=o)
+        st.synchronize()
+        assert bool(torch.isfinite(d_s[::31, ::37]).all())
+        worst_abs, worst_psnr, rng_max = 0.0, 1e9, 0.0
+        for (yy, xx), want in zip(spots, wants):
+            got = d_s[2 * yy:2 * yy + 144, 2 * xx:2 * xx + 144].cpu().numpy()
+            worst_abs = max(worst_abs, float(np.abs(got - want).max()))
+            worst_psnr = min(worst_psnr, psnr(got, want))
+            rng_max = max(rng_max, float(np.abs(want).max()))
+            if name == "fp32":
+                assert_close(got, want, "cfg4 fp32 patch (%d,%d)" % (yy, xx))
+        report[name] = (worst_abs, worst_psnr, rng_max)
+    print("cfg4 cascade vs CPU fp32 (max abs err, min PSNR dB, max |want|):", report)
+    assert report["bf16"][0] <= BF16_MAX_ABS and report["bf16"][1] >= BF16_PSNR_DB, report
+    assert report["fp16x2"][0] <= FP16X2_REL_RANGE * report["fp16x2"][2], report
+
+
+def test_cfg5_wide_model_2048(gpu):
+    """BASELINE.json configs[4]: 3->128->128->128->128->128->128->3 on three 2048x2048 planes (multi-plane wrapper: pad 7,
+    7 layers, crop), patches vs the oracle's Model::filter chain"""
+    import torch
+    layers = gen_model.synth_layers(gen_model.TOPOLOGY_WIDE, gen_model.SEEDS["wide"])
+    ms = gpu._ModelSet.from_layers(layers)
+    h = w = 2048
+    x = np.random.default_rng(5).random((3, h, w), dtype=np.float32)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty((3, h, w), device="cuda")
+    st = torch.cuda.current_stream()
+    ms.convert_planes_device(3, d_in.data_ptr(), h * w * 4, w * 4, w, h, d_out.data_ptr(), h * w * 4, w * 4, stream=st.cuda_stream,
+                             opts=gpu.make_opts(device=0))
+    st.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.isfinite(got).all()
+    o = orc.Oracle(layers)
+    for (yy, xx) in [(0, 0), (h - 40, w - 40), (0, 1000), (1023, 1023), (h - 40, 3), (700, w - 40)]:
+        y0, y1, x0, x1 = max(0, yy - 7), min(h, yy + 40 + 7), max(0, xx - 7), min(w, xx + 40 + 7)
+        # replicate-pad 7 where the crop touches the plane border (the wrapper pads the PLANE, interior crop edges are margin)
+        crop = x[:, y0:y1, x0:x1]
+        pt, pb, pl, pr = (7 if y0 == 0 else 0), (7 if y1 == h else 0), (7 if x0 == 0 else 0), (7 if x1 == w else 0)
+        t = np.pad(crop, ((0, 0), (pt, pb), (pl, pr)), mode="edge")
+        for l in range(7):
+            t = o.filter(l, t, njob=8)
+        t = t[:, 7:-7, 7:-7]                                   # same-size filters: the 7-px rim is contaminated, drop it
+        oy, ox = y0 - pt + 7, x0 - pl + 7                        # plane coordinates of t[:, 0, 0]
+        want = t[:, yy - oy:yy - oy + 40, xx - ox:xx - ox + 40]
+        assert_close(got[:, yy:yy + 40, xx:xx + 40], want, "cfg5 patch (%d,%d)" % (yy, xx))
+
+
+@pytest.mark.parametrize("init", ["upstream", "wide_range"])
+@pytest.mark.parametrize("amp", [1.0, 1.0 / 255.0])
+def test_weight_statistics_fp32_and_fp16x2(gpu, init, amp):
+    """the 7-layer topology with (a) the init the shipped models were trained from (srcnn.lua:5-9: N(0, sqrt(2/(9 nOut))), bias 0)
+    and (b) a 10^3 weight dynamic range with 30 % exactly-zero kernels and large biases -- on a full-range plane and on a
+    very dark one (all values <= 1/255).  fp32 MFMA: the north-star tolerance.  FP16X2: its stated bound (relative to the
+    output range).  The direct kernel stays bit-exact (zero taps must not change anything)."""
+    layers = gen_model.synth_layers(seed=33, init=init)
+    ms = gpu._ModelSet.from_layers(layers)
+    x = rand_plane(150, 210, 9) * np.float32(amp)
+    want = orc.Oracle(layers).convert(x, njob=8)
+    assert_close(ms.convert(x), want, "%s fp32" % init)
+    assert np.array_equal(ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_DIRECT)), want)
+    got = ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_FP16X2))
+    rng = float(np.abs(want).max())
+    err = float(np.abs(got - want).max())
+    print("%s amp %g: FP16X2 max err / range = %.3g (range %.3g)" % (init, amp, err / rng, rng))
+    assert err <= FP16X2_REL_RANGE * rng, (init, amp, err / rng)

@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 from conftest import ATOL, RTOL, assert_close, ramp_plane, rand_plane, small_layers
-from oracle import gen_model, oracle as orc
+from tools import gen_model
+from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -643,7 +644,7 @@ def test_host_multi_band_path(gpu, scale_layers, tmp_path):
     from conftest import ROOT
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "import __graft_entry__ as g; from tools import gen_model\n"
         "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
         "x = np.random.default_rng(4).random((101, 77), dtype=np.float32)\n"
         "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert_nn2x(x)[:101, :77]]))\n" % ROOT)
@@ -664,7 +665,7 @@ def test_default_precision_from_environment(gpu, scale_layers, tmp_path):
     from conftest import ROOT
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "import __graft_entry__ as g; from tools import gen_model\n"
         "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
         "x = np.random.default_rng(4).random((64, 96), dtype=np.float32)\n"
         "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert(x, opts=w.make_opts(precision=w.PRECISION_BF16X3)),\n"
@@ -702,7 +703,7 @@ def test_fused_last_layer_vs_unfused(gpu, tmp_path):
     from conftest import ROOT
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "import __graft_entry__ as g; from tools import gen_model\n"
         "w = g.load_package(); outs = []; flags = []\n"
         "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 1], 7), ([1, 64, 32, 1], 8)):\n"
         "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
@@ -735,7 +736,7 @@ def test_bf16_first_generation_kernels_still_work(gpu, tmp_path):
     from conftest import ROOT
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from oracle import gen_model, oracle as orc\n"
+        "import __graft_entry__ as g; from tools import gen_model; from oracle import oracle as orc\n"
         "w = g.load_package(); layers = gen_model.synth_layers(seed=102); ms = w._ModelSet.from_layers(layers)\n"
         "x = np.random.default_rng(3).random((96, 128), dtype=np.float32)\n"
         "o = w.make_opts(precision=w.PRECISION_BF16)\n"
@@ -760,7 +761,7 @@ def test_fused_first_two_layers_vs_unfused(gpu, tmp_path):
     from conftest import ROOT
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from oracle import gen_model\n"
+        "import __graft_entry__ as g; from tools import gen_model\n"
         "w = g.load_package(); outs = []; flags = []\n"
         "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 32, 1], 7), ([1, 32, 128, 64, 1], 8), ([1, 32, 32, 3], 9)):\n"
         "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"

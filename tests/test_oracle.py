@@ -16,7 +16,8 @@ import numpy as np
 import pytest
 
 from conftest import ramp_plane, rand_plane, small_layers
-from oracle import gen_model, oracle as orc
+from tools import gen_model
+from oracle import oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 

@@ -19,7 +19,8 @@ def _worker(rank, world, port, tmpdir, h, w):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as graft
-    from oracle import gen_model, oracle as orc
+    from tools import gen_model
+    from oracle import oracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +51,8 @@ def _worker(rank, world, port, tmpdir, h, w):
 def test_two_rank_row_band_shard_matches_unsharded(oracle_built, tmp_path, h, w):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
-    from oracle import gen_model, oracle as orc
+    from tools import gen_model
+    from oracle import oracle as orc
     port = 29600 + (os.getpid() % 300) + h
     mp.spawn(_worker, args=(2, port, str(tmp_path), h, w), nprocs=2, join=True)
     got = np.load(str(tmp_path / "stitched.npy"))

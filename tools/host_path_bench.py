@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-from oracle import gen_model
+from tools import gen_model
 import bench
 w2xc = graft.load_package()
 ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"]))

@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import __graft_entry__ as graft  # noqa: E402
-from oracle import gen_model, oracle as orc  # noqa: E402
+from tools import gen_model
+from oracle import oracle as orc  # noqa: E402
 
 w2xc = graft.load_package()
 out = {"device": torch.cuda.get_device_name(0), "host_cores": os.cpu_count()}

@@ -8,7 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as graft
-from oracle import gen_model
+from tools import gen_model
 w2xc = graft.load_package()
 ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(seed=102))
 bad = 0

@@ -18,12 +18,15 @@ sys.path.insert(0, ROOT)
 
 def plan_scale(ratio):
     """(iterations, shrink_ratio) exactly as main.cpp:107-114 computes them (shrink 0.0 = none)."""
-    it = int(math.ceil(math.log2(ratio))) if ratio > 0 else 0
-    it = max(it, 0)
+    if not ratio > 0:
+        raise ValueError("scale_ratio must be positive")
+    it = int(math.ceil(math.log2(ratio)))        # may be NEGATIVE for ratio < 1: the reference does not clamp it (:107-108)
     shrink = 0.0
-    if int(ratio) != 2 ** it:                     # static_cast<int>(ratio) != std::pow(2, iter)
-        shrink = ratio / 2.0 ** it
-    return it, shrink
+    if int(ratio) != 2.0 ** it:                   # static_cast<int>(ratio) != std::pow(2, iter)
+        shrink = ratio / 2.0 ** it                # e.g. ratio 0.3 -> iter -1 -> shrink 0.6 (NOT 0.3), ratio 0.5 -> shrink 1.0
+    if shrink == 1.0:
+        shrink = 0.0                              # cv::resize to the same size with INTER_LINEAR is the identity
+    return max(it, 0), shrink                     # the 2x loop runs max(iter, 0) times (:126)
 
 
 def auto_output_name(input_file, mode, noise_level, scale_ratio):
@@ -77,7 +80,7 @@ def main(argv=None):
         raise SystemExit("scale_ratio %g needs no 2x step; the reference would only shrink, which is not supported without a model pass" % args.scale_ratio)
     else:
         prec = {"fp32": w2xc.PRECISION_FP32, "bf16": w2xc.PRECISION_BF16, "bf16x2": w2xc.PRECISION_BF16X2, "bf16x3": w2xc.PRECISION_BF16X3, "fp16x2": w2xc.PRECISION_FP16X2}[args.precision]
-        opts = w2xc.make_opts(precision=prec) if prec != w2xc.PRECISION_FP32 else None
+        opts = w2xc.make_opts(precision=prec)      # always explicit: an explicit --precision beats the W2XC_PRECISION env default
         out = w2xc.process_image_u8(bgr, noise, scale if iterations else None, iterations, opts, shrink)
     name = args.output_file
     if name == "(auto)":

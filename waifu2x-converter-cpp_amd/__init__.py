@@ -42,7 +42,7 @@ class Opts(C.Structure):
     """struct w2xc_opts (include/w2xc_hip.h)."""
     _fields_ = [("struct_size", C.c_int), ("precision", C.c_int), ("kernel", C.c_int), ("device", C.c_int),
                 ("device_mask", C.c_uint), ("band_rows", C.c_int), ("workspace_mb", C.c_int),
-                ("profile", C.c_int), ("verbose", C.c_int)]
+                ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int)]
 
 
 def _load():
@@ -87,6 +87,9 @@ def _load():
         "w2xc_yuv_to_u8_device": (ci, [fp, fp, fp, ci, ci, fp, cs, vp]),
         "w2xc_convert_plane_nn2x": (ci, [vp, fp, cs, ci, ci, fp, cs, C.POINTER(Opts)]),
         "w2xc_convert_plane_nn2x_device": (ci, [vp, fp, cs, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
+        "w2xc_convert_plane_rows": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, ci, fp, cs, C.POINTER(Opts)]),
+        "w2xc_layer_filter_device": (ci, [vp, ci, ci, fp, C.c_longlong, C.c_longlong, C.c_longlong, ci, ci, fp, C.c_longlong,
+                                          C.c_longlong, C.c_longlong, vp, C.POINTER(Opts)]),
         "w2xc_convert_rows_device": (ci, [vp, fp, cs, ci, ci, ci, ci, ci, ci, fp, cs, vp, C.POINTER(Opts)]),
         "w2xc_layer_filter": (ci, [vp, ci, ci, C.POINTER(fp), cs, ci, ci, C.POINTER(fp), cs, C.POINTER(Opts)]),
         "w2xc_profile_read": (ci, [vp, ci, C.POINTER(C.c_float), C.POINTER(ci), ci]),
@@ -295,6 +298,29 @@ class _ModelSet:
         rc = _lib.w2xc_convert_rows_device(self.handle, C.c_void_p(d_view), view_stride_bytes, view_h, view_y0, w,
                                            plane_h, row_begin, row_end, C.c_void_p(d_out), out_stride_bytes,
                                            C.c_void_p(stream), C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+
+    def convert_rows(self, view, view_y0, plane_h, row_begin, row_end, nn2x=0, opts=None, out=None):
+        """One unit of the tile farm from HOST memory (w2xc_convert_plane_rows): `view` holds source rows
+        [view_y0, view_y0 + len(view)) of a plane_h-row source plane; returns output rows [row_begin, row_end) (in
+        output coordinates: of the 2x plane when nn2x = 1)."""
+        src = Mat(view)
+        w = src.cols
+        if out is None:
+            out = np.empty((row_end - row_begin, w << nn2x), np.float32)
+        rc = _lib.w2xc_convert_plane_rows(self.handle, src.array.ctypes.data, src.step, view_y0, src.rows, w, plane_h, nn2x,
+                                          row_begin, row_end, out.ctypes.data, out.strides[0],
+                                          C.byref(opts) if opts is not None else None)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+        return out
+
+    def filter_device(self, layer, n_in, d_in, in_strides, w, h, d_out, out_strides, stream=0, opts=None):
+        """Model::filter on device data; *_strides = (plane, row, pixel) element strides in floats (w2xc_layer_filter_device)."""
+        rc = _lib.w2xc_layer_filter_device(self.handle, layer, n_in, C.c_void_p(d_in), in_strides[0], in_strides[1], in_strides[2], w, h,
+                                           C.c_void_p(d_out), out_strides[0], out_strides[1], out_strides[2], C.c_void_p(stream),
+                                           C.byref(opts) if opts is not None else None)
         if rc != OK:
             raise W2xcError(rc, last_error())
 

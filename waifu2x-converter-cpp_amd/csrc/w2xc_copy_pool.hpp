@@ -1,0 +1,118 @@
+// w2xc_copy_pool.hpp -- the host-side gather/scatter workers of the tile farm.
+//
+// The reference stitches block interiors into the output plane with cv::Mat::copyTo on one thread
+// (/root/reference/src/convertRoutine.cpp:143-161) and spends modelUtility's nJob threads on the
+// convolutions (src/modelHandler.cpp:42-69).  Here the convolutions are on the GPU, so nJob is spent
+// where the host still has work: copying the caller's pageable planes into / out of the pinned
+// staging rings that feed the H2D / D2H streams (SURVEY 8b "map nJob to host staging threads").
+//
+// A tiny persistent pool: copy_rows() splits one strided row copy into `parts` contiguous row ranges,
+// the caller takes part in its own job, idle workers help.  Several device threads may submit at once.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace w2xc_host {
+
+class CopyPool {
+public:
+    static CopyPool &get()
+    {
+        static CopyPool *p = new CopyPool();   // leaked on purpose: workers may outlive static destruction
+        return *p;
+    }
+
+    // dst/src rows are `row_bytes` long, `ds` / `ss` bytes apart.  nthreads <= 1 copies inline.
+    void copy_rows(char *dst, size_t ds, const char *src, size_t ss, size_t row_bytes, int rows, int nthreads)
+    {
+        if (rows <= 0 || row_bytes == 0) return;
+        const size_t total = row_bytes * (size_t)rows;
+        int parts = nthreads;
+        if ((size_t)parts > total / (256u << 10)) parts = (int)(total / (256u << 10));   // >= 256 KiB per part
+        if (parts > rows) parts = rows;
+        if (parts <= 1) {
+            run(dst, ds, src, ss, row_bytes, 0, rows);
+            return;
+        }
+        ensure_threads(parts - 1);
+        auto j = std::make_shared<Job>();
+        j->dst = dst; j->ds = ds; j->src = src; j->ss = ss; j->rb = row_bytes; j->rows = rows; j->parts = parts;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.push_back(j);
+        }
+        cv_.notify_all();
+        work_on(*j);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return j->done.load() == j->parts; });
+    }
+
+private:
+    struct Job {
+        char *dst; size_t ds; const char *src; size_t ss; size_t rb; int rows, parts;
+        std::atomic<int> next{0}, done{0};
+    };
+
+    static void run(char *dst, size_t ds, const char *src, size_t ss, size_t rb, int r0, int r1)
+    {
+        if (ds == rb && ss == rb) {
+            memcpy(dst + (size_t)r0 * rb, src + (size_t)r0 * rb, (size_t)(r1 - r0) * rb);
+            return;
+        }
+        for (int r = r0; r < r1; r++) memcpy(dst + (size_t)r * ds, src + (size_t)r * ss, rb);
+    }
+
+    void work_on(Job &j)
+    {
+        for (;;) {
+            const int p = j.next.fetch_add(1);
+            if (p >= j.parts) return;
+            const int r0 = (int)((long long)j.rows * p / j.parts), r1 = (int)((long long)j.rows * (p + 1) / j.parts);
+            run(j.dst, j.ds, j.src, j.ss, j.rb, r0, r1);
+            if (j.done.fetch_add(1) + 1 == j.parts) {
+                std::lock_guard<std::mutex> lk(mu_);   // pairs with the submitter's predicate check
+                done_cv_.notify_all();
+            }
+        }
+    }
+
+    void ensure_threads(int n)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (n > 31) n = 31;
+        while ((int)th_.size() < n) {
+            th_.emplace_back([this] { worker(); });
+            th_.back().detach();
+        }
+    }
+
+    void worker()
+    {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                j = q_.front();
+                if (j->next.load() >= j->parts) {   // fully handed out: retire it from the queue
+                    q_.pop_front();
+                    continue;
+                }
+            }
+            work_on(*j);
+        }
+    }
+
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::shared_ptr<Job>> q_;
+    std::vector<std::thread> th_;
+};
+
+}  // namespace w2xc_host
