@@ -460,7 +460,8 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
 
 // Hooks of the host->host tile farm into the band loop (all optional; enqueue-only, never synchronise the device):
 struct BandHooks {
-    int out_chunk_rows = 0;                              // > 0: the last layer of a band is launched in row chunks of this size
+    int out_chunk_rows = 0;                              // > 0: the last layer of a band is launched in row chunks of at most this size,
+    int out_chunk_min = 0;                               //      tapering to this size at the end of the band (the exposed D2H tail)
     std::function<int(int, int)> input_needed;           // before layer 1 of band [y0, y1): make the launch stream wait for its input rows
     std::function<int(int, int)> prefetch;               // layers 1..n-1 of the current band are enqueued; [y0, y1) = the NEXT band
     std::function<int(int, int)> output_ready;           // output rows [r0, r1) have been enqueued on the launch stream
@@ -624,13 +625,18 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 int rc = hk->prefetch(y1, std::min(rb, y1 + band));
                 if (rc) return rc;
             }
-            const bool chunked = hk && k == n && direct_out && hk->out_chunk_rows > 0 && d.out_h > hk->out_chunk_rows &&
+            const bool chunked = hk && k == n && direct_out && hk->out_chunk_rows > 0 && d.out_h > std::max(hk->out_chunk_min, 8) &&
                                  (kind == W2XC_K_LAST || kind == W2XC_K_LAST_GATHER || kind == W2XC_K_LAST_BF16IN || kind == W2XC_K_DIRECT);
             if (chunked) {
                 // the last layer in row chunks: chunk j's rows leave for the host while chunk j+1 is computed
-                for (int c0 = 0; c0 < d.out_h; c0 += hk->out_chunk_rows) {
+                for (int c0 = 0, cr = 0; c0 < d.out_h; c0 += cr) {
+                    // a third of what is left, within [min, max], in whole 8-row tiles: big chunks while there is compute
+                    // left to hide their D2H behind, small ones at the end where the D2H is exposed
+                    const int left = d.out_h - c0;
+                    cr = std::min(hk->out_chunk_rows, std::max(std::max(hk->out_chunk_min, 8), ((left / 3) + 7) & ~7));
+                    if (left - cr < std::max(hk->out_chunk_min, 8)) cr = left;
                     W2xcConvDesc dd = d;
-                    dd.out_h = std::min(hk->out_chunk_rows, d.out_h - c0);
+                    dd.out_h = cr;
                     dd.out = d.out + (size_t)c0 * d.out_rs;
                     if (kind == W2XC_K_LAST_GATHER) dd.in = d.in + (size_t)c0 * d.in_rs;   // no offsets in that kernel
                     else dd.off_y = d.off_y + c0;
@@ -994,14 +1000,16 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     const size_t in_row = (size_t)w * 4, out_row = (size_t)W * 4;
     const bool in_pinned = host_range_pinned((const char *)in + (size_t)sy0 * in_stride, (size_t)(svh - 1) * in_stride + in_row);
     const bool out_pinned = host_range_pinned((const char *)out + (size_t)ra * out_stride, (size_t)(rb - ra - 1) * out_stride + out_row);
-    // staging granularity: ~2 MiB, whole rows; output chunks are multiples of the 8-row tiles of the last-layer kernels
-    const size_t chunk_target = [] {
+    // staging granularity, whole rows: input slices of ~2 MiB; output chunks of at most ~8 MiB tapering to 1/16 of that
+    // (multiples of the 8-row tiles of the last-layer kernels).  W2XC_HOST_CHUNK_KB overrides the maximum (test aid).
+    const size_t chunk_max = [] {
         const char *e = getenv("W2XC_HOST_CHUNK_KB");
         const long v = e ? atol(e) : 0;
-        return v > 0 ? (size_t)v << 10 : (size_t)2 << 20;
+        return v > 0 ? (size_t)v << 10 : (size_t)8 << 20;
     }();
-    const int in_chunk_rows = (int)std::max<size_t>(1, chunk_target / in_row);
-    int out_chunk_rows = (int)std::max<size_t>(8, (chunk_target / out_row) & ~(size_t)7);
+    const int in_chunk_rows = (int)std::max<size_t>(1, std::min<size_t>(chunk_max, (size_t)2 << 20) / in_row);
+    const int out_chunk_rows = (int)std::max<size_t>(8, (chunk_max / out_row) & ~(size_t)7);
+    const int out_chunk_min = (int)std::max<size_t>(8, (chunk_max / 16 / out_row) & ~(size_t)7);
     rc = pipe_reserve(p, (size_t)svh * in_row, (size_t)(rb - ra) * out_row, in_pinned ? 0 : (size_t)in_chunk_rows * in_row,
                       out_pinned ? 0 : (size_t)out_chunk_rows * out_row);
     if (rc) return rc;
@@ -1085,6 +1093,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
 
     BandHooks hk;
     hk.out_chunk_rows = out_chunk_rows;
+    hk.out_chunk_min = out_chunk_min;
     hk.input_needed = [&](int, int y1) -> int {
         int r = upload_to(band_src_end(y1));
         if (r) return r;

@@ -238,10 +238,14 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
 //   of stage t+1 are read BEFORE the barrier and the MFMA stream runs across it.
 // ------------------------------------------------------------------------------------------------
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int EPI = 1>
-__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
+// SWAP = 1: the MFMA operands are exchanged (A = weights, B = pixels), so the accumulator tile is transposed: a lane owns
+// ONE pixel (column = lane & 31) and, per register quad, 4 CONSECUTIVE output planes (row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// The epilogue then stores 16 bytes per lane (4 stores per 32x32 block instead of 16) and the accumulators start at the bias
+// instead of zero (no bias add in the epilogue): 2.75 instead of 5 non-MFMA instructions per output value.
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int SWAP = 0, int EPI = 1>
+__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles, int flags)
 {
-    constexpr int NST = MB * NB * 16;                // stores per wave in an interior-tile epilogue
+    constexpr int NST = MB * NB * (SWAP ? 4 : 16);   // stores per wave in an interior-tile epilogue
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
     constexpr int NSL = CIN / 32, NBT = COUT / 32;
     constexpr int NW = WM * WN;                      // 4 waves (one per SIMD) or 8 (two per SIMD)
@@ -261,6 +265,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nb0 = wn * NB;
     const int li = lane & 31, kk = lane >> 5;
+    // two waves per SIMD: the second-dispatched half loses every issue arbitration by age; one static priority bump for
+    // it (never flipped) evens the pair out (MI355X_MICROARCH.md "Two waves per SIMD", item 4)
+    if (WM * WN == 8 && (flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the tile list
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
@@ -271,8 +278,24 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     if (tile >= chunk_end) return;
 
     float bv[NB];
+    // SWAP: the 16 planes of block nb this lane owns are 8*q + 4*kk + e.  With 8 accumulator blocks per wave (512-register
+    // configurations) the bias quads stay in LDS and are read in the epilogue; otherwise they live in registers.
+    constexpr bool BIAS_LDS = SWAP && MB * NB >= 8;
+    constexpr unsigned BIAS_BASE = B_BASE + 4 * B_BYTES;
+    f32x4 bq[(SWAP && !BIAS_LDS) ? NB : 1][4];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bv[nb] = d.bias[(nb0 + nb) * 32 + li];
+    if (SWAP && !BIAS_LDS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[nb][q] = *reinterpret_cast<const f32x4 *>(d.bias + (nb0 + nb) * 32 + 8 * q + 4 * kk);
+    }
+    if (BIAS_LDS && threadIdx.x < COUT) lds[BIAS_BASE / 4 + threadIdx.x] = d.bias[threadIdx.x];   // visible after the prologue barrier
+    auto bias_quad = [&](int nb, int q) -> f32x4 {
+        if (BIAS_LDS) return *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * q + 4 * kk) * 4);
+        return bq[BIAS_LDS ? 0 : nb][q];
+    };
 
     // ---- per-lane DMA source offsets of the A halo tile (16-byte units), piece jj of this wave ----
     const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
@@ -344,12 +367,6 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     };
 
     f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
 
     // ---- prologue: A(slice 0) and B stages 0..2 of the first tile ----
     tile_offsets(tile);
@@ -360,7 +377,18 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 #pragma unroll
         for (int jb = 0; jb < BPW; jb++) dma_b((t / 9) % NSL, t % 9, t & 3, jb);
     W2XC_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();   // (also publishes the bias vector in LDS)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (SWAP) b4 = bias_quad(nb, q);
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[mb][nb][4 * q + e] = b4[e];
+        }
 
     unsigned gs = 0;      // global stage counter (only gs & 3 matters): ring slot of the current stage
     unsigned abuf = 0;    // A buffer of the current slice
@@ -411,7 +439,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nb][j], a_cur[mb][j], acc[mb][nb], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
                             const int m = (j * MB + mb) * NB + nb;        // MFMA index in the step
                             if (c8 == 0 && (m == 1 || m == 3) && (m >> 1) < KA[tap]) {
                                 __builtin_amdgcn_sched_barrier(0);
@@ -466,7 +495,30 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
             const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
             const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
             float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
-            if (interior) {
+            if (SWAP) {
+                // lane = pixel ox0 + li; registers 4q .. 4q+3 = planes 32*nb + 8q + 4kk .. +3 (accumulated on top of the bias)
+                float *ob = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * COUT + nb0 * 32 + 4 * kk;
+                const bool xin = ox0 + li < d.out_w;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f32x4 b4 = bias_quad(nb, q);
+#pragma unroll
+                        for (int mb = 0; mb < MB; mb++) {
+                            const bool ok = interior || (xin && oy0 + wm * MB + mb < d.out_h);
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float t = acc[mb][nb][4 * q + e];
+                                v[e] = fmaxf(t, 0.1f * t);
+                                acc[mb][nb][4 * q + e] = b4[e];
+                            }
+                            if (ok) *reinterpret_cast<f32x4 *>(ob + (long long)mb * d.out_rs + nb * 32 + 8 * q) = v;
+                        }
+                    }
+                epi_stores = interior;
+            } else if (interior) {
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -665,32 +717,46 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
         for (int mb = 0; mb < MB; mb++) a[mb][s] = lds[(wave * MB + mb) * HW + i + off];
     }
 
+    // Operands swapped (weights = MFMA A, pixels = B): the accumulator tile is [plane][pixel], a lane owns pixel ox0 + i and
+    // per register quad q the 4 consecutive planes 32*nb + 8q + 4kk .. +3 -> one 16-byte (fp32) / 8-byte (bf16) store per
+    // quad instead of 4 scattered dwords; the accumulators start at the bias.
 #pragma unroll 1
     for (int nb = 0; nb < NBT; nb++) {
         float b[S];
 #pragma unroll
         for (int s = 0; s < S; s++) b[s] = d.wpk[(nb * S + s) * 64 + lane];
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(d.bias + nb * 32 + 8 * q + 4 * kk);
         f32x16 acc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][r] = 0.0f;
+            for (int r = 0; r < 16; r++) acc[mb][r] = bq[r >> 2][r & 3];
 #pragma unroll
         for (int s = 0; s < S; s++)
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][s], b[s], acc[mb], 0, 0, 0);
-        const int n = nb * 32 + i;
-        const float bv = d.bias[n];
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[mb][s], acc[mb], 0, 0, 0);
+        const int x = ox0 + i;
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) {
             const int y = oy0 + wave * MB + mb;
-            if (y < d.out_h) {
-                OutT *orow = reinterpret_cast<OutT *>(d.out) + (long long)y * d.out_rs + n;
+            if (y < d.out_h && x < d.out_w) {
+                OutT *op = reinterpret_cast<OutT *>(d.out) + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * kk;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    if (x < d.out_w) store_act(orow + (long long)x * COUT, leaky(acc[mb][r] + bv));
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e]);
+                    if (sizeof(OutT) == 4) {
+                        *reinterpret_cast<f32x4 *>(op + 8 * q) = v;
+                    } else {
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *reinterpret_cast<uint2 *>(op + 8 * q) = pk;
+                    }
                 }
             }
         }
@@ -923,14 +989,20 @@ static hipError_t launch_mfma(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int SWAP>
+static hipError_t launch_mfma2_(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
     constexpr int NW = WM * WN;
-    const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024);
-    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN>;
+    const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024) + (size_t)COUT * 4;
+    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, SWAP>;
     // > 64 KiB of dynamic LDS needs the opt-in attribute, and function attributes are per DEVICE
     // (the in-process multi-GPU path launches this kernel on several devices from several threads)
     static std::atomic<unsigned long long> attr_done{0};
@@ -944,8 +1016,17 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
+    static const int flags = env_int("W2XC_MFMA_PRIO", 1) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles, flags);
     return hipGetLastError();
+}
+
+// W2XC_MFMA_SWAP (tuning aid): 1 (default) = transposed accumulator tile, 16-byte epilogue stores; 0 = the first epilogue
+template <int CIN, int COUT, int MB, int NB, int WM, int WN>
+static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
+{
+    static const int swap = env_int("W2XC_MFMA_SWAP", 1);
+    return swap ? launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 1>(d, stream) : launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 0>(d, stream);
 }
 
 // W2XC_MFMA_V2 (tuning aid): unset = default tilings, 0 = force conv3x3_mfma (v1), 1 = conv3x3_mfma2 with 4 waves
