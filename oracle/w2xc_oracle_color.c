@@ -10,17 +10,46 @@
  *   :171  cv::cvtColor(image, image, cv::COLOR_YUV2RGB)
  *   :172  image.convertTo(image, CV_8U, 255.0)              (the only clip in the pipeline, Q2)
  *
- * PARITY UNPINNED: these are OpenCV 3.0 imgproc/core functions (un-vendored, absent here, no golden
- * vectors in the reference).  Restated from OpenCV's documented float paths:
- *   convertTo 8U->32F:  (float)u * (float)(1/255.0)   [cvtScale_ with a float work type]
- *   RGB2YUV (float):    Y = c0*0.299f + c1*0.587f + c2*0.114f; U = (c2 - Y)*0.492f + 0.5f; V = (c0 - Y)*0.877f + 0.5f
- *                       (channel 0 is whatever the caller calls "R"; dst order Y,U,V)
- *   YUV2RGB (float):    c2 = Y + (U-0.5f)*2.032f; c1 = Y + (U-0.5f)*-0.395f + (V-0.5f)*-0.581f; c0 = Y + (V-0.5f)*1.140f
- *   convertTo 32F->8U:  saturate_cast<uchar>(cvRound(v * 255.f))   (round half to even)
- *   resize INTER_CUBIC: fx = (dx+0.5)*0.5 - 0.5; sx = floor(fx); t = fx - sx; Keys cubic with A = -0.75;
- *                       taps sx-1..sx+2 with indices clipped to the image (replicate); horizontal pass
- *                       to float rows, then vertical pass; each pass is a left-to-right sum of 4 products.
- *   resize INTER_NEAREST 2x: src(y>>1, x>>1).
+ * PARITY PINNING STATUS.  These are OpenCV 3.0 core/imgproc functions; OpenCV is un-vendored and absent here and the
+ * reference holds no golden vectors, so the formulas below are restated from the OpenCV 3.0 sources AS REMEMBERED (no copy
+ * of the tree is reachable offline) and each one is cross-checked against an INDEPENDENT implementation in
+ * tests/test_oracle_color.py.  What each restatement follows, and what pins it:
+ *
+ *   convertTo 8U->32F    modules/core/src/convert.cpp, cvtScale_<uchar, float, float>: dst = saturate_cast<float>(src*scale
+ *                        + shift) with scale narrowed to the float work type: (float)u * (float)(1/255.0).
+ *                        Pinned by: numpy float32 product (bit-exact), test_convert_to_float.
+ *   cvtColor RGB2YUV     modules/imgproc/src/color.cpp, RGB2YCrCb_f<float> built with the YUV coefficient table
+ *     (float)             {0.114f, 0.587f, 0.299f, 0.492f, 0.877f} for blueIdx 2... i.e. with channel 0 = "R":
+ *                        Y = c0*0.299f + c1*0.587f + c2*0.114f;  U = (c2 - Y)*0.492f + 0.5f;  V = (c0 - Y)*0.877f + 0.5f
+ *                        (delta = 0.5f for float images; dst order Y, U, V).  The CLI feeds imread's BGR bytes, so "c0" is
+ *                        really blue (quirk Q3) -- irrelevant here, the formula is applied to the channels as given.
+ *                        Pinned by: an fp64 numpy matrix form of the documented equations (OpenCV docs, "RGB <-> YUV":
+ *                        Y = 0.299R + 0.587G + 0.114B, U = 0.492(B - Y) + 0.5, V = 0.877(R - Y) + 0.5), test_yuv_matrix.
+ *   cvtColor YUV2RGB     color.cpp, YCrCb2RGB_f<float> with {2.032f, -0.395f, -0.581f, 1.140f}:
+ *     (float)             c2 = Y + (U-0.5f)*2.032f;  c1 = Y + (U-0.5f)*-0.395f + (V-0.5f)*-0.581f;  c0 = Y + (V-0.5f)*1.140f
+ *                        Pinned by: the same fp64 matrix form inverted, and the u8 -> YUV -> u8 identity on all sampled bytes.
+ *   convertTo 32F->8U    convert.cpp, cvtScale_<float, uchar, float>: saturate_cast<uchar>(cvRound(v*255.f)); cvRound is
+ *                        lrint / _mm_cvtss_si32 under the default rounding mode = round half to EVEN; saturate_cast clips
+ *                        to [0, 255].  Pinned by: numpy rint on exact .5 products and the clip cases, test_round_saturate.
+ *   resize INTER_NEAREST modules/imgproc/src/imgwarp.cpp, resizeNN: sx = min(cvFloor(dx * (1/fx)), sw-1) = dx >> 1 for 2x.
+ *                        Pinned by: np.repeat.
+ *   resize INTER_CUBIC   imgwarp.cpp, resizeGeneric_ with HResizeCubic / VResizeCubic and interpolateCubic():
+ *                        fx = (dx+0.5)*scale - 0.5; sx = cvFloor(fx); t = fx - sx; A = -0.75f;
+ *                        c0 = ((A*(t+1) - 5A)*(t+1) + 8A)*(t+1) - 4A;  c1 = ((A+2)*t - (A+3))*t*t + 1;
+ *                        c2 = ((A+2)*(1-t) - (A+3))*(1-t)*(1-t) + 1;  c3 = 1 - c0 - c1 - c2;
+ *                        taps sx-1..sx+2, indices clipped to [0, sw-1] (border replicate); float work type for CV_32F:
+ *                        horizontal pass into float rows, then the vertical pass; each a left-to-right 4-term sum.
+ *                        Pinned by: torch F.interpolate(mode="bicubic", align_corners=False) (independent code, A = -0.75,
+ *                        half-pixel centres, clamped taps) at 2x on several sizes incl. 1-pixel-wide planes, test_cubic.
+ *   resize INTER_LINEAR  imgwarp.cpp, resizeGeneric_ with HResizeLinear / VResizeLinear: fx = (dx+0.5)*scale - 0.5;
+ *                        sx = cvFloor(fx); fx -= sx; sx < 0 -> (0, 0); sx >= sw-1 -> (sw-1, 0); weights (1-fx, fx).
+ *                        Pinned by: torch F.interpolate(mode="bilinear", align_corners=False, antialias=False) for the
+ *                        CLI's shrink ratios (0.75, 0.625, 0.6 ...) and an enlargement, test_linear.
+ *
+ * STILL UNPINNED (cannot be settled without an OpenCV 3.0.0-rc1 build): (1) whether 3.0.0-rc1 pairs the U / V coefficients
+ * and output order exactly as above (later 3.x releases touched the YUV channel order); (2) bit-level summation order of
+ * the SSE/AVX paths of the resize passes and of cvtColor versus the scalar order restated here (differences <= 1 float ulp
+ * per pass; the independent checks above hold to 1e-6); (3) cvRound under a non-default MXCSR rounding mode.
  * Compile with -ffp-contract=off.
  */
 #include <math.h>
