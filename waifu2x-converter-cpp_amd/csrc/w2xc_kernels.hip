@@ -238,14 +238,15 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
 //   of stage t+1 are read BEFORE the barrier and the MFMA stream runs across it.
 // ------------------------------------------------------------------------------------------------
 
-// SWAP = 1: the MFMA operands are exchanged (A = weights, B = pixels), so the accumulator tile is transposed: a lane owns
-// ONE pixel (column = lane & 31) and, per register quad, 4 CONSECUTIVE output planes (row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-// The epilogue then stores 16 bytes per lane (4 stores per 32x32 block instead of 16) and the accumulators start at the bias
-// instead of zero (no bias add in the epilogue): 2.75 instead of 5 non-MFMA instructions per output value.
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int SWAP = 0, int EPI = 1>
-__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles, int flags)
+//   Epilogue (DEFER = 1): a tile's accumulators are NOT stored when its last stage ends.  They are stored during the FIRST
+//   STEP of the next tile, block by block: that step runs block-major, and the bias-free epilogue of block i (16 x {mul,
+//   max, store} + 16 re-initialisations to the bias) is issued right before block i's own 4 MFMAs, i.e. in the shadow of
+//   block i-1's MFMAs.  Only the first block's epilogue (and the very last tile's) is exposed; with one wave per SIMD the
+//   epilogue was otherwise 1 % (128->128) to 7 % (32->32, K = 288) of a tile.  Accumulators start at the bias.
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int DEFER = 1, int EPI = 1>
+__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
 {
-    constexpr int NST = MB * NB * (SWAP ? 4 : 16);   // stores per wave in an interior-tile epilogue
+    constexpr int NST = MB * NB * 16;                // stores per wave in an interior-tile epilogue
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
     constexpr int NSL = CIN / 32, NBT = COUT / 32;
     constexpr int NW = WM * WN;                      // 4 waves (one per SIMD) or 8 (two per SIMD)
@@ -265,9 +266,6 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nb0 = wn * NB;
     const int li = lane & 31, kk = lane >> 5;
-    // two waves per SIMD: the second-dispatched half loses every issue arbitration by age; one static priority bump for
-    // it (never flipped) evens the pair out (MI355X_MICROARCH.md "Two waves per SIMD", item 4)
-    if (WM * WN == 8 && (flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the tile list
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
@@ -278,24 +276,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     if (tile >= chunk_end) return;
 
     float bv[NB];
-    // SWAP: the 16 planes of block nb this lane owns are 8*q + 4*kk + e.  With 8 accumulator blocks per wave (512-register
-    // configurations) the bias quads stay in LDS and are read in the epilogue; otherwise they live in registers.
-    constexpr bool BIAS_LDS = SWAP && MB * NB >= 8;
-    constexpr unsigned BIAS_BASE = B_BASE + 4 * B_BYTES;
-    f32x4 bq[(SWAP && !BIAS_LDS) ? NB : 1][4];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bv[nb] = d.bias[(nb0 + nb) * 32 + li];
-    if (SWAP && !BIAS_LDS) {
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) bq[nb][q] = *reinterpret_cast<const f32x4 *>(d.bias + (nb0 + nb) * 32 + 8 * q + 4 * kk);
-    }
-    if (BIAS_LDS && threadIdx.x < COUT) lds[BIAS_BASE / 4 + threadIdx.x] = d.bias[threadIdx.x];   // visible after the prologue barrier
-    auto bias_quad = [&](int nb, int q) -> f32x4 {
-        if (BIAS_LDS) return *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * q + 4 * kk) * 4);
-        return bq[BIAS_LDS ? 0 : nb][q];
-    };
 
     // ---- per-lane DMA source offsets of the A halo tile (16-byte units), piece jj of this wave ----
     const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
@@ -367,6 +349,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     };
 
     f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mb][nb][r] = bv[nb];   // the accumulators start at the bias
 
     // ---- prologue: A(slice 0) and B stages 0..2 of the first tile ----
     tile_offsets(tile);
@@ -377,18 +365,44 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 #pragma unroll
         for (int jb = 0; jb < BPW; jb++) dma_b((t / 9) % NSL, t % 9, t & 3, jb);
     W2XC_WAIT_VMCNT(0);
-    __syncthreads();   // (also publishes the bias vector in LDS)
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue of one accumulator block: LeakyReLU (= max(v, 0.1 v)) + NHWC stores in 128-byte runs, then the block
+    //      restarts at the bias.  C/D map: column = lane & 31 (plane), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel). ----
+    //      Addressing: a wave-uniform base (SGPR pair) + ONE tile-independent 32-bit lane offset per 8-pixel group + an
+    //      immediate, so the deferred epilogue keeps no per-tile address registers alive inside the MFMA loop.
+    float *e_base = nullptr;      // wave-uniform: first pixel / first plane of this wave's part of the tile being stored
+    int e_rows = 0, e_cols = 0;   // valid rows / columns of that tile (from this wave's first row / the tile's first column)
+    bool e_interior = false, e_pending = false;
+    unsigned e_off[4];            // float offset of (pixel 8g + 4kk, plane li) inside a row-block
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++)
+    for (int g = 0; g < 4; g++) e_off[g] = (unsigned)((8 * g + 4 * kk) * COUT + li);
+    auto epi_block = [&](int mb, int nb) {
+        float *o = e_base + (long long)mb * d.out_rs + nb * 32;   // uniform
+        if (e_interior) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (SWAP) b4 = bias_quad(nb, q);
+            for (int r = 0; r < 16; r++) {
+                const float v = acc[mb][nb][r];
+                o[e_off[r >> 2] + (r & 3) * COUT] = fmaxf(v, 0.1f * v);
+                acc[mb][nb][r] = bv[nb];
+            }
+        } else {
 #pragma unroll
-            for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc[mb][nb][4 * q + e] = b4[e];
+            for (int r = 0; r < 16; r++) {
+                const float v = acc[mb][nb][r];
+                if (mb < e_rows && (r & 3) + 8 * (r >> 2) + 4 * kk < e_cols) o[e_off[r >> 2] + (r & 3) * COUT] = fmaxf(v, 0.1f * v);
+                acc[mb][nb][r] = bv[nb];
+            }
         }
+    };
+    auto epi_begin = [&](int t) {   // describe tile t for the epilogue (all wave-uniform)
+        const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
+        const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+        e_interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
+        e_base = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)ox0 * COUT + nb0 * 32;
+        e_rows = d.out_h - (oy0 + wm * MB);
+        e_cols = d.out_w - ox0;
+    };
 
     unsigned gs = 0;      // global stage counter (only gs & 3 matters): ring slot of the current stage
     unsigned abuf = 0;    // A buffer of the current slice
@@ -433,14 +447,50 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                 const unsigned abuf_n = (wrap && tap == 8) ? (abuf ^ 1u) : abuf;
                 const unsigned bbuf_n = wrap ? buf1 : buf;
                 f32x4 a_nxt[MB], b_nxt[NB];
+                // the first step of a tile after a deferred epilogue runs block-major with the previous tile's stores in
+                // between (see DEFER above); every other step j-major (4 k-steps of one fragment back to back per block)
+                const bool epi_now = DEFER && tap == 0 && c8 == 0 && e_pending;
+                if (DEFER && tap == 0 && c8 == 0 && epi_now) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            epi_block(mb, nb);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
+                                const int m = (mb * NB + nb) * 4 + j;         // MFMA index in the step
+                                if ((m == 1 || m == 3) && (m >> 1) < KA[tap]) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    dma_a(a_add, abuf ^ 1u, ja0 + (m >> 1));
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                                if (m == 5 && c8 < BPW) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    dma_b(sl3, tap3, buf3, c8);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+#pragma unroll
+                                for (int r = 0; r < R; r++) {
+                                    if (m == 1 + (r * (M - 5)) / R) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
+                                        else b_nxt[r - MB] = *b_addr(bbuf_n, c8_n, r - MB);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                }
+                            }
+                        }
+                    e_pending = false;
+                    epi_stores = e_interior;   // exactly NST stores are now queued among this stage's transfers
+                } else
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
-                            acc[mb][nb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nb][j], a_cur[mb][j], acc[mb][nb], 0, 0, 0)
-                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
                             const int m = (j * MB + mb) * NB + nb;        // MFMA index in the step
                             if (c8 == 0 && (m == 1 || m == 3) && (m >> 1) < KA[tap]) {
                                 __builtin_amdgcn_sched_barrier(0);
@@ -488,63 +538,15 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         abuf ^= 1u;
 
         if (last_slice) {
-            // ---- epilogue: bias + LeakyReLU, NHWC stores (C/D: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)).
-            //      leaky(v) = max(v, 0.1f*v).  Interior tiles (all but the last row / column of tiles)
-            //      take the unpredicated path. ----
-            const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-            const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-            const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
-            float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
-            if (SWAP) {
-                // lane = pixel ox0 + li; registers 4q .. 4q+3 = planes 32*nb + 8q + 4kk .. +3 (accumulated on top of the bias)
-                float *ob = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * COUT + nb0 * 32 + 4 * kk;
-                const bool xin = ox0 + li < d.out_w;
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const f32x4 b4 = bias_quad(nb, q);
-#pragma unroll
-                        for (int mb = 0; mb < MB; mb++) {
-                            const bool ok = interior || (xin && oy0 + wm * MB + mb < d.out_h);
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const float t = acc[mb][nb][4 * q + e];
-                                v[e] = fmaxf(t, 0.1f * t);
-                                acc[mb][nb][4 * q + e] = b4[e];
-                            }
-                            if (ok) *reinterpret_cast<f32x4 *>(ob + (long long)mb * d.out_rs + nb * 32 + 8 * q) = v;
-                        }
-                    }
-                epi_stores = interior;
-            } else if (interior) {
+            epi_begin(tile);
+            if (DEFER) {
+                e_pending = true;          // stored under the first step of the next tile (or after the loop)
+            } else {
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const float v = acc[mb][nb][r] + bv[nb];
-                            obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
-                            acc[mb][nb][r] = 0.0f;
-                        }
-                epi_stores = true;
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++) {
-                    const int y = oy0 + wm * MB + mb;
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                            const float v = acc[mb][nb][r] + bv[nb];
-                            if (y < d.out_h && x < d.out_w)
-                                obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
-                            acc[mb][nb][r] = 0.0f;
-                        }
-                }
+                    for (int nb = 0; nb < NB; nb++) epi_block(mb, nb);
+                epi_stores = e_interior;
             }
             tile += per;
             if (tile >= chunk_end) break;
@@ -552,6 +554,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         } else {
             sl++;
         }
+    }
+    if (DEFER && e_pending) {
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) epi_block(mb, nb);
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative DMAs before the LDS is released
 }
@@ -995,14 +1003,14 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int SWAP>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int DEFER>
 static hipError_t launch_mfma2_(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
     constexpr int NW = WM * WN;
-    const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024) + (size_t)COUT * 4;
-    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, SWAP>;
+    const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024);
+    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, DEFER>;
     // > 64 KiB of dynamic LDS needs the opt-in attribute, and function attributes are per DEVICE
     // (the in-process multi-GPU path launches this kernel on several devices from several threads)
     static std::atomic<unsigned long long> attr_done{0};
@@ -1016,17 +1024,16 @@ static hipError_t launch_mfma2_(const W2xcConvDesc &d, hipStream_t stream)
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
-    static const int flags = env_int("W2XC_MFMA_PRIO", 1) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles, flags);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
     return hipGetLastError();
 }
 
-// W2XC_MFMA_SWAP (tuning aid): 1 (default) = transposed accumulator tile, 16-byte epilogue stores; 0 = the first epilogue
+// W2XC_MFMA_DEFER (tuning aid): 1 (default) = a tile's stores run under the next tile's first step; 0 = at the tile's end
 template <int CIN, int COUT, int MB, int NB, int WM, int WN>
 static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
 {
-    static const int swap = env_int("W2XC_MFMA_SWAP", 1);
-    return swap ? launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 1>(d, stream) : launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 0>(d, stream);
+    static const int defer = env_int("W2XC_MFMA_DEFER", 1);
+    return defer ? launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 1>(d, stream) : launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 0>(d, stream);
 }
 
 // W2XC_MFMA_V2 (tuning aid): unset = default tilings, 0 = force conv3x3_mfma (v1), 1 = conv3x3_mfma2 with 4 waves
