@@ -2,8 +2,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [B, E).  Register arrays indexed through a lambda PARAMETER
+// end up in scratch memory even under #pragma unroll; indices that arrive as integral constants never do.
+template <int B, int E, class F>
+static __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

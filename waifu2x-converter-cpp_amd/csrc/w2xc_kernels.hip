@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
     unsigned e_off[4];            // float offset of (pixel 8g + 4kk, plane li) inside a row-block
 #pragma unroll
     for (int g = 0; g < 4; g++) e_off[g] = (unsigned)((8 * g + 4 * kk) * COUT + li);
-    auto epi_block = [&](int mb, int nb) {
+    auto epi_block = [&](auto MBI, auto NBI) {   // (block indices as integral constants: see static_for)
+        constexpr int mb = decltype(MBI)::value, nb = decltype(NBI)::value;
         float *o = e_base + (long long)mb * d.out_rs + nb * 32;   // uniform
         if (e_interior) {
 #pragma unroll
@@ -451,11 +452,10 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                 // between (see DEFER above); every other step j-major (4 k-steps of one fragment back to back per block)
                 const bool epi_now = DEFER && tap == 0 && c8 == 0 && e_pending;
                 if (DEFER && tap == 0 && c8 == 0 && epi_now) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++) {
-                            epi_block(mb, nb);
+                    static_for<0, MB * NB>([&](auto BI) {
+                        constexpr int mb = decltype(BI)::value / NB, nb = decltype(BI)::value % NB;
+                        {
+                            epi_block(std::integral_constant<int, mb>{}, std::integral_constant<int, nb>{});
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
@@ -481,6 +481,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                                 }
                             }
                         }
+                    });
                     e_pending = false;
                     epi_stores = e_interior;   // exactly NST stores are now queued among this stage's transfers
                 } else
@@ -542,10 +543,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
             if (DEFER) {
                 e_pending = true;          // stored under the first step of the next tile (or after the loop)
             } else {
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) epi_block(mb, nb);
+                static_for<0, MB * NB>([&](auto BI) {
+                    epi_block(std::integral_constant<int, decltype(BI)::value / NB>{}, std::integral_constant<int, decltype(BI)::value % NB>{});
+                });
                 epi_stores = e_interior;
             }
             tile += per;
@@ -556,10 +556,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         }
     }
     if (DEFER && e_pending) {
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) epi_block(mb, nb);
+        static_for<0, MB * NB>([&](auto BI) {
+            epi_block(std::integral_constant<int, decltype(BI)::value / NB>{}, std::integral_constant<int, decltype(BI)::value % NB>{});
+        });
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative DMAs before the LDS is released
 }

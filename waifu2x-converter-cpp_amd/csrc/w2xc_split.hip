@@ -138,15 +138,6 @@ template <int T, int MB, int NB> static __device__ constexpr int read_decode(int
     return -1;
 }
 
-// compile-time loop: f(std::integral_constant<int, i>) for i in [B, E)
-template <int B, int E, class F>
-static __device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 // A-piece schedule: APW pieces spread (ceil first) over taps 0..LASTA
 template <int APW, int LASTA> static __device__ constexpr int ka(int t) { return t <= LASTA ? (APW + LASTA - t) / (LASTA + 1) : 0; }
 template <int APW, int LASTA> static __device__ constexpr int ka_before(int tap)
