@@ -7,6 +7,8 @@ Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries:
 FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE reports 1/2 of wide streaming reads
 (MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024."""
 import csv, json, os, shutil, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash
 base, prefix = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 T = {"fp32": 0, "bf16x2": 2, "bf16x3": 3, "fp16x2": 2, "bf16": 1}[prec]
@@ -23,7 +25,8 @@ def mean_counter(path, sub, counter):
     return sum(v) / len(v) if v else None
 
 stats = {r["Name"]: r for r in csv.DictReader(open(base + "trace/trace_kernel_stats.csv"))}
-out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-precisions%s (tools/profile.sh)" % ("" if T == 0 else " --precision " + prec),
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-host%s (tools/profile.sh)" % ("" if T == 0 else " --precision " + prec),
+       "kernel_source_hash": kernel_source_hash(),   # bench.py only quotes `traffic` from this file while the sources still hash to this
        "note": __doc__.split("FETCH_SIZE", 1)[1].strip().replace("\n", " "), "kernels": {}}
 for k, (cin, cout) in enumerate(PLANES, 1):
     if T == 0:

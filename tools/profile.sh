@@ -3,12 +3,12 @@
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2..: PMC counters, each in its
 # own run with --kernel-trace only (never combined with sys/hip/hsa tracing).
 # Results land in gpurun_out/prof_<tag>/ ; copy the summaries to profiles/ afterwards.
-TAG=${1:-r1}
+TAG=${1:-r2}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-precisions $W2XC_BENCH_ARGS"   # e.g. W2XC_BENCH_ARGS="--precision bf16x3"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-host $W2XC_BENCH_ARGS"   # e.g. W2XC_BENCH_ARGS="--precision bf16x3"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc --output-format csv -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -238,12 +238,7 @@ __global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int 
 //   of stage t+1 are read BEFORE the barrier and the MFMA stream runs across it.
 // ------------------------------------------------------------------------------------------------
 
-//   Epilogue (DEFER = 1): a tile's accumulators are NOT stored when its last stage ends.  They are stored during the FIRST
-//   STEP of the next tile, block by block: that step runs block-major, and the bias-free epilogue of block i (16 x {mul,
-//   max, store} + 16 re-initialisations to the bias) is issued right before block i's own 4 MFMAs, i.e. in the shadow of
-//   block i-1's MFMAs.  Only the first block's epilogue (and the very last tile's) is exposed; with one wave per SIMD the
-//   epilogue was otherwise 1 % (128->128) to 7 % (32->32, K = 288) of a tile.  Accumulators start at the bias.
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int DEFER = 1, int EPI = 1>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int EPI = 1>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int NST = MB * NB * 16;                // stores per wave in an interior-tile epilogue
@@ -354,7 +349,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][nb][r] = bv[nb];   // the accumulators start at the bias
+            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
 
     // ---- prologue: A(slice 0) and B stages 0..2 of the first tile ----
     tile_offsets(tile);
@@ -366,44 +361,6 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         for (int jb = 0; jb < BPW; jb++) dma_b((t / 9) % NSL, t % 9, t & 3, jb);
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue of one accumulator block: LeakyReLU (= max(v, 0.1 v)) + NHWC stores in 128-byte runs, then the block
-    //      restarts at the bias.  C/D map: column = lane & 31 (plane), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel). ----
-    //      Addressing: a wave-uniform base (SGPR pair) + ONE tile-independent 32-bit lane offset per 8-pixel group + an
-    //      immediate, so the deferred epilogue keeps no per-tile address registers alive inside the MFMA loop.
-    float *e_base = nullptr;      // wave-uniform: first pixel / first plane of this wave's part of the tile being stored
-    int e_rows = 0, e_cols = 0;   // valid rows / columns of that tile (from this wave's first row / the tile's first column)
-    bool e_interior = false, e_pending = false;
-    unsigned e_off[4];            // float offset of (pixel 8g + 4kk, plane li) inside a row-block
-#pragma unroll
-    for (int g = 0; g < 4; g++) e_off[g] = (unsigned)((8 * g + 4 * kk) * COUT + li);
-    auto epi_block = [&](auto MBI, auto NBI) {   // (block indices as integral constants: see static_for)
-        constexpr int mb = decltype(MBI)::value, nb = decltype(NBI)::value;
-        float *o = e_base + (long long)mb * d.out_rs + nb * 32;   // uniform
-        if (e_interior) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float v = acc[mb][nb][r];
-                o[e_off[r >> 2] + (r & 3) * COUT] = fmaxf(v, 0.1f * v);
-                acc[mb][nb][r] = bv[nb];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float v = acc[mb][nb][r];
-                if (mb < e_rows && (r & 3) + 8 * (r >> 2) + 4 * kk < e_cols) o[e_off[r >> 2] + (r & 3) * COUT] = fmaxf(v, 0.1f * v);
-                acc[mb][nb][r] = bv[nb];
-            }
-        }
-    };
-    auto epi_begin = [&](int t) {   // describe tile t for the epilogue (all wave-uniform)
-        const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
-        const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-        e_interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
-        e_base = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)ox0 * COUT + nb0 * 32;
-        e_rows = d.out_h - (oy0 + wm * MB);
-        e_cols = d.out_w - ox0;
-    };
 
     unsigned gs = 0;      // global stage counter (only gs & 3 matters): ring slot of the current stage
     unsigned abuf = 0;    // A buffer of the current slice
@@ -448,43 +405,6 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                 const unsigned abuf_n = (wrap && tap == 8) ? (abuf ^ 1u) : abuf;
                 const unsigned bbuf_n = wrap ? buf1 : buf;
                 f32x4 a_nxt[MB], b_nxt[NB];
-                // the first step of a tile after a deferred epilogue runs block-major with the previous tile's stores in
-                // between (see DEFER above); every other step j-major (4 k-steps of one fragment back to back per block)
-                const bool epi_now = DEFER && tap == 0 && c8 == 0 && e_pending;
-                if (DEFER && tap == 0 && c8 == 0 && epi_now) {
-                    static_for<0, MB * NB>([&](auto BI) {
-                        constexpr int mb = decltype(BI)::value / NB, nb = decltype(BI)::value % NB;
-                        {
-                            epi_block(std::integral_constant<int, mb>{}, std::integral_constant<int, nb>{});
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j], acc[mb][nb], 0, 0, 0);
-                                const int m = (mb * NB + nb) * 4 + j;         // MFMA index in the step
-                                if ((m == 1 || m == 3) && (m >> 1) < KA[tap]) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    dma_a(a_add, abuf ^ 1u, ja0 + (m >> 1));
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                                if (m == 5 && c8 < BPW) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    dma_b(sl3, tap3, buf3, c8);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-#pragma unroll
-                                for (int r = 0; r < R; r++) {
-                                    if (m == 1 + (r * (M - 5)) / R) {
-                                        __builtin_amdgcn_sched_barrier(0);
-                                        if (r < MB) a_nxt[r] = *a_addr(abuf_n, r, tap_n, c8_n);
-                                        else b_nxt[r - MB] = *b_addr(bbuf_n, c8_n, r - MB);
-                                        __builtin_amdgcn_sched_barrier(0);
-                                    }
-                                }
-                            }
-                        }
-                    });
-                    e_pending = false;
-                    epi_stores = e_interior;   // exactly NST stores are now queued among this stage's transfers
-                } else
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -539,14 +459,40 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         abuf ^= 1u;
 
         if (last_slice) {
-            epi_begin(tile);
-            if (DEFER) {
-                e_pending = true;          // stored under the first step of the next tile (or after the loop)
+            // ---- epilogue: bias + LeakyReLU, NHWC stores (C/D: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)).
+            //      leaky(v) = max(v, 0.1f*v).  Interior tiles (all but the last row / column of tiles)
+            //      take the unpredicated path. ----
+            const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+            const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+            const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
+            float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
+            if (interior) {
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float v = acc[mb][nb][r] + bv[nb];
+                            obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                            acc[mb][nb][r] = 0.0f;
+                        }
+                epi_stores = true;
             } else {
-                static_for<0, MB * NB>([&](auto BI) {
-                    epi_block(std::integral_constant<int, decltype(BI)::value / NB>{}, std::integral_constant<int, decltype(BI)::value % NB>{});
-                });
-                epi_stores = e_interior;
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) {
+                    const int y = oy0 + wm * MB + mb;
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                            const float v = acc[mb][nb][r] + bv[nb];
+                            if (y < d.out_h && x < d.out_w)
+                                obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                            acc[mb][nb][r] = 0.0f;
+                        }
+                }
             }
             tile += per;
             if (tile >= chunk_end) break;
@@ -554,11 +500,6 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         } else {
             sl++;
         }
-    }
-    if (DEFER && e_pending) {
-        static_for<0, MB * NB>([&](auto BI) {
-            epi_block(std::integral_constant<int, decltype(BI)::value / NB>{}, std::integral_constant<int, decltype(BI)::value % NB>{});
-        });
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative DMAs before the LDS is released
 }
@@ -996,20 +937,14 @@ static hipError_t launch_mfma(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int DEFER>
-static hipError_t launch_mfma2_(const W2xcConvDesc &d, hipStream_t stream)
+template <int CIN, int COUT, int MB, int NB, int WM, int WN>
+static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
     constexpr int NW = WM * WN;
     const size_t lds_bytes = 2 * (size_t)(NW * ((43 + NW) / NW) * 1024) + 4 * (size_t)(4 * (COUT / 32) * 1024);
-    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN, DEFER>;
+    auto kern = conv3x3_mfma2<CIN, COUT, MB, NB, WM, WN>;
     // > 64 KiB of dynamic LDS needs the opt-in attribute, and function attributes are per DEVICE
     // (the in-process multi-GPU path launches this kernel on several devices from several threads)
     static std::atomic<unsigned long long> attr_done{0};
@@ -1025,14 +960,6 @@ static hipError_t launch_mfma2_(const W2xcConvDesc &d, hipStream_t stream)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
     return hipGetLastError();
-}
-
-// W2XC_MFMA_DEFER (tuning aid): 1 (default) = a tile's stores run under the next tile's first step; 0 = at the tile's end
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
-{
-    static const int defer = env_int("W2XC_MFMA_DEFER", 1);
-    return defer ? launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 1>(d, stream) : launch_mfma2_<CIN, COUT, MB, NB, WM, WN, 0>(d, stream);
 }
 
 // W2XC_MFMA_V2 (tuning aid): unset = default tilings, 0 = force conv3x3_mfma (v1), 1 = conv3x3_mfma2 with 4 waves
@@ -1074,11 +1001,12 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
         // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0 (conv3x3_mfma, the first-generation
-        // kernel, kept as a fallback).  Measured inside the 7-layer model: 8 waves (two per SIMD) win on
-        // 128->128 only, 4 waves elsewhere (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
+        // kernel, kept as a fallback).  Measured inside the 7-layer model (round 2, same box, same run): 8 waves (two per
+        // SIMD) win on every 128-plane output (64->128: -3.5 %, 128->128: -2 %) and on 32->64 (-1.4 %), tie on 64->64, lose
+        // on 32->32 (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
         const int v2 = mfma_v2_enabled();
         if (v2 != 0) {
-            const bool w8 = (v2 == 3) || (v2 < 0 && key == 128128);
+            const bool w8 = (v2 == 3) || (v2 < 0 && (d.cout == 128 || key == 32064));
             switch (key) {
             //                                  CIN  COUT  MB NB WM WN
             case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
