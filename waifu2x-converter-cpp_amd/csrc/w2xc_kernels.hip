@@ -1002,11 +1002,12 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         const int key = d.cin * 1000 + d.cout;
         // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0 (conv3x3_mfma, the first-generation
         // kernel, kept as a fallback).  Measured inside the 7-layer model (round 2, same box, same run): 8 waves (two per
-        // SIMD) win on every 128-plane output (64->128: -3.5 %, 128->128: -2 %) and on 32->64 (-1.4 %), tie on 64->64, lose
-        // on 32->32 (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
+        // SIMD: the partner's MFMAs cover this wave's non-MFMA issue slots) win wherever the output has >= 64 planes
+        // (32->64 -1.8 %, 64->64 -2.5 %, 64->128 -2.9 %, 128->128 -2.9 %); 32->32 has one plane block, so its 8 waves would
+        // split rows only (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
         const int v2 = mfma_v2_enabled();
         if (v2 != 0) {
-            const bool w8 = (v2 == 3) || (v2 < 0 && (d.cout == 128 || key == 32064));
+            const bool w8 = (v2 == 3) || (v2 < 0 && d.cout >= 64);
             switch (key) {
             //                                  CIN  COUT  MB NB WM WN
             case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
