@@ -896,6 +896,7 @@ int w2xc_split_halves(int terms, int cout)
     if (terms == 1) {   // (must mirror launch_split_t's choice of WN)
         static const int cfg = [] { const char *e = getenv("W2XC_SPLIT_T1_CFG"); return e ? atoi(e) : 0; }();
         if (cfg == 1) return 1;
+        if (cfg == 2) return cout >= 128 ? 2 : 1;
     }
     return terms == 2 ? (cout >= 64 ? 2 : 1) : (cout >= 128 ? 2 : 1);
 }
@@ -1060,14 +1061,23 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         // (4x2 / 4x4 accumulator blocks), 32-channel stages, ring of 6: a fragment read then feeds 1.5-2x the MFMAs -- the
         // 32-cycle bf16 MFMAs of the 8-row tiling draw 96 of the LDS's 128 bytes per clock in fragment reads alone.
         static const int cfg = [] { const char *e = getenv("W2XC_SPLIT_T1_CFG"); return e ? atoi(e) : 0; }();
-        if (cfg == 1) {
+        if (cfg == 2) {   // 128-plane outputs: 16 rows, 8 waves (two per SIMD), 4x2 blocks
+            switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
+#endif
+            case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
+            default: break;
+            }
+        }
+        if (cfg >= 1) {
             switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV
             case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
             case 64064:  return launch_split<64, 64, 4, 2, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
-            case 64128:  return launch_split<64, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
+            case 64128:  if (cfg == 1) return launch_split<64, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream); break;
 #endif
-            case 128128: return launch_split<128, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
+            case 128128: if (cfg == 1) return launch_split<128, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream); break;
             default: break;
             }
         }
