@@ -891,15 +891,7 @@ hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
 }
 
 // wave columns (WN) of the two-term tile shape for `cout` planes = partial-G planes the fused epilogue writes
-int w2xc_split_halves(int terms, int cout)
-{
-    if (terms == 1) {   // (must mirror launch_split_t's choice of WN)
-        static const int cfg = [] { const char *e = getenv("W2XC_SPLIT_T1_CFG"); return e ? atoi(e) : 0; }();
-        if (cfg == 1) return 1;
-        if (cfg == 2) return cout >= 128 ? 2 : 1;
-    }
-    return terms == 2 ? (cout >= 64 ? 2 : 1) : (cout >= 128 ? 2 : 1);
-}
+int w2xc_split_halves(int terms, int cout) { return terms == 2 ? (cout >= 64 ? 2 : 1) : (cout >= 128 ? 2 : 1); }
 
 size_t w2xc_split_pack_last_bytes(int cin, int terms) { return (size_t)terms * (cin / 32) * 2 * 64 * 8 * 2; }
 
@@ -1057,35 +1049,17 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
     if constexpr (T == 1) {
-        // One term.  W2XC_SPLIT_T1_CFG=1 (tuning aid): 16 rows x 32 px, 4 waves that each own ALL output planes of 4 rows
-        // (4x2 / 4x4 accumulator blocks), 32-channel stages, ring of 6: a fragment read then feeds 1.5-2x the MFMAs -- the
-        // 32-cycle bf16 MFMAs of the 8-row tiling draw 96 of the LDS's 128 bytes per clock in fragment reads alone.
-        static const int cfg = [] { const char *e = getenv("W2XC_SPLIT_T1_CFG"); return e ? atoi(e) : 0; }();
-        if (cfg == 2) {   // 128-plane outputs: 16 rows, 8 waves (two per SIMD), 4x2 blocks
-            switch (d.cin * 1000 + d.cout) {
-#ifndef W2XC_SPLIT_DEV
-            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
-#endif
-            case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
-            default: break;
-            }
-        }
-        if (cfg >= 1) {
-            switch (d.cin * 1000 + d.cout) {
-#ifndef W2XC_SPLIT_DEV
-            case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
-            case 64064:  return launch_split<64, 64, 4, 2, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
-            case 64128:  if (cfg == 1) return launch_split<64, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream); break;
-#endif
-            case 128128: if (cfg == 1) return launch_split<128, 128, 4, 4, 4, 1, 1, OT, 2, 6, FMT>(d, stream); break;
-            default: break;
-            }
-        }
-        // default: 8 rows x 32 px, 4 waves, 64-channel stages (32 for cin = 32), ring of 4
+        // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
+        // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
+        //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
+        //             0.56 -> 0.39 ms per 2160x3840 layer (a fragment read feeds 1.5x the MFMAs, weights stream once per 16 rows)
+        //   128->128  16 rows, 8 waves (two per SIMD), 4x2 blocks, 32-channel stages, ring of 6: 2.40 -> 2.13 ms
+        //   64->64, 64->128 and the rest: 8 rows, 4 waves, 64-channel stages, ring of 4 (the 16-row forms measured equal / 5 % slower;
+        //             4x4 blocks for 128 planes spill ~290 registers and run 3x slower)
         switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV
         case 32032:  return launch_split<32, 32, 2, 1, 4, 1, 1, OT, 2, 4, FMT>(d, stream);
-        case 32064:  return launch_split<32, 64, 2, 2, 4, 1, 1, OT, 2, 4, FMT>(d, stream);
+        case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 6, FMT>(d, stream);
         case 32128:  return launch_split<32, 128, 4, 2, 2, 2, 1, OT, 2, 4, FMT>(d, stream);
         case 64032:  return launch_split<64, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
@@ -1093,7 +1067,7 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         case 128032: return launch_split<128, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 128064: return launch_split<128, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
 #endif
-        case 128128: return launch_split<128, 128, 4, 2, 2, 2, 1, OT, 4, 4, FMT>(d, stream);
+        case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
         default: return hipErrorInvalidValue;
         }
     }
