@@ -154,7 +154,14 @@ template <int APW, int LASTA> static __device__ constexpr int ka_window(int tap,
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
+// E = stages per EPOCH: the workgroup barrier (and the counted vmcnt wait in front of it) closes every E-th stage instead of
+// every stage.  A 16-bit stage is 16-48 MFMAs of 32 cycles per wave -- 0.5 to 1.5k cycles, an eighth of an fp32 stage -- so a
+// barrier per stage costs these kernels what it never cost conv3x3_mfma2.  Inside an epoch the waves drift up to E stages
+// apart, which the ring has to absorb:  B(t + LEAD) is issued during stage t with LEAD = RING - E (the slot it overwrites
+// belongs to a stage of an EARLIER epoch, which every wave has left), and the barrier that closes stage t needs B(t + E + 1)
+// landed (the last step of a stage already reads the next stage's first fragments), i.e. the transfer issued
+// LOOK = RING - 2E - 1 stages ago.  E = 1 is the original schedule; E = 3 (9 taps = 3 epochs per slice) wants RING = 8.
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT, int E = 1>
 __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = MB * WM;                     // 8 or 16 output rows per tile
@@ -176,14 +183,15 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr unsigned B_BYTES = B_PIECES * 1024;
     constexpr unsigned B_BASE = 2 * A_BYTES;
     constexpr int NP = Prod<T>::N;
-    constexpr int LEAD = RING - 1;                    // B(t + LEAD) is issued during stage t
-    constexpr int LOOK = RING - 3;                    // stages whose transfers are younger than B(t+2) at the end of stage t
-    constexpr int LASTA = 10 - RING < 5 ? 10 - RING : 5;   // A pieces of the next slice are issued on taps 0..LASTA: landed by the end of tap 7,
-                                                           // because tap 8's last step already reads the next slice's first fragments
+    constexpr int LEAD = RING - E;                    // B(t + LEAD) is issued during stage t
+    constexpr int LOOK = RING - 2 * E - 1;            // stages whose transfers are younger than B(t+E+1) at the barrier that closes stage t
+    constexpr int LASTA = 9 - LEAD < 5 ? 9 - LEAD : 5;     // A pieces of the next slice are issued on taps 0..LASTA: landed by the last barrier
+                                                           // before tap 8 ends (tap 8's last step already reads the next slice's first
+                                                           // fragments): that barrier waits for B(9), issued in tap 9 - LEAD after the tap's A pieces
     constexpr int NST = OT == 9 ? MB * 5 : MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
     static_assert((NW == 4 || NW == 8) && (ROWS == 8 || ROWS == 16) && NB * WN == NBT, "tile shape");
     static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
-    static_assert(RING >= 4 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
+    static_assert((E == 1 || E == 3) && RING >= 2 * E + 2 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c];   // visible after the prologue barrier
     // OT == 9 (last layer fused into this epilogue): its weights as MFMA A fragments, [term][plane block][k-group][lane][8]
     constexpr unsigned W7_BASE = BIAS_BASE + COUT * 4;
-    constexpr bool W7_IN_LDS = (T == 2);   // (the one-term shapes have no LDS left: fragments come from L2 instead)
+    constexpr bool W7_IN_LDS = (T == 2 && E == 1);   // (the one-term and 8-slot shapes have no LDS left: fragments come from L2 instead)
     if constexpr (OT == 9 && W7_IN_LDS) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(d.w7pk);
         u32x4 *dst = reinterpret_cast<u32x4 *>(const_cast<char *>(ldsb) + W7_BASE);
@@ -439,7 +447,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             // stage boundary: B(t+2) -- issued LOOK stages ago -- must have landed; the only younger transfers
             // are the ones issued since (vmcnt retires in order).  For the first LOOK stages after an interior
             // epilogue the NST stores are younger than B(t+2) too and are counted in rather than drained.
-            {
+            if constexpr ((tap + 1) % E == 0) {
                 constexpr int n_dma = ka_window<APW, LASTA>(tap, LOOK) + LOOK * BPW;
                 if (tap < LOOK && sl == 0 && epi_stores) wait_vmcnt_n(n_dma + NST);
                 else wait_vmcnt_n(n_dma);
@@ -1012,7 +1020,7 @@ float w2xc_split_pack(int cin, int cout, int terms, int fmt, const float *w, voi
 }
 #endif
 
-template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT>
+template <int CIN, int COUT, int MB, int NB, int WM, int WN, int T, int OT, int KG, int RING, int FMT, int E = 1>
 static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr int ROWS = MB * WM, NPIXP = ((ROWS + 2) * 34 + 31) / 32 * 32;
@@ -1021,9 +1029,9 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     constexpr int NW = WM * WN;
     constexpr int A_PIECES = T * NPIXP * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
     constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4 +
-                                 ((OT == 9 && T == 2) ? 4 * (COUT / 32) * 1024 : 0);
+                                 ((OT == 9 && T == 2 && E == 1) ? 4 * (COUT / 32) * 1024 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT>;
+    auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT, E>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1048,7 +1056,19 @@ template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
+    static const int epoch = [] { const char *e = getenv("W2XC_SPLIT_EPOCH"); return e ? atoi(e) : 1; }();
     if constexpr (T == 1) {
+        if (epoch == 3) {   // (tuning aid) one barrier per 3 taps, ring of 8
+            switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+            case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 8, FMT, 3>(d, stream);
+            case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 2, 8, FMT, 3>(d, stream);
+            case 64128:  return launch_split<64, 128, 4, 2, 2, 2, 1, OT, 2, 8, FMT, 3>(d, stream);
+#endif
+            case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 8, FMT, 3>(d, stream);
+            default: break;
+            }
+        }
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
@@ -1072,6 +1092,19 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         }
     }
     constexpr int KG = 1, RG = 6;
+    if constexpr (BIG) {
+        if (epoch == 3) {   // (tuning aid) two terms: one barrier per 3 taps, ring of 8
+            switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+            case 32064:  return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
+            case 64064:  return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
+            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
+#endif
+            case 128128: return launch_split<128, 128, 4, 2, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
+            default: break;
+            }
+        }
+    }
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                     CIN  COUT  MB NB WM WN
