@@ -1056,24 +1056,14 @@ template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
-    static const int epoch = [] { const char *e = getenv("W2XC_SPLIT_EPOCH"); return e ? atoi(e) : 1; }();
     if constexpr (T == 1) {
-        if (epoch == 3) {   // (tuning aid) one barrier per 3 taps, ring of 8
-            switch (d.cin * 1000 + d.cout) {
-#ifndef W2XC_SPLIT_DEV
-            case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 8, FMT, 3>(d, stream);
-            case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 2, 8, FMT, 3>(d, stream);
-            case 64128:  return launch_split<64, 128, 4, 2, 2, 2, 1, OT, 2, 8, FMT, 3>(d, stream);
-#endif
-            case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 8, FMT, 3>(d, stream);
-            default: break;
-            }
-        }
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
         //             0.56 -> 0.39 ms per 2160x3840 layer (a fragment read feeds 1.5x the MFMAs, weights stream once per 16 rows)
-        //   128->128  16 rows, 8 waves (two per SIMD), 4x2 blocks, 32-channel stages, ring of 6: 2.40 -> 2.13 ms
+        //   128->128  16 rows, 8 waves (two per SIMD), 4x2 blocks, 32-channel stages: 2.40 -> 2.13 ms; and one workgroup barrier
+        //             per 3 taps instead of per tap (E = 3, ring of 8): -> 2.02 ms.  The epoch schedule measured SLOWER on the
+        //             other shapes (their 64-channel stages do not fit a ring of 8) and equal on the two-term kernels.
         //   64->64, 64->128 and the rest: 8 rows, 4 waves, 64-channel stages, ring of 4 (the 16-row forms measured equal / 5 % slower;
         //             4x4 blocks for 128 planes spill ~290 registers and run 3x slower)
         switch (d.cin * 1000 + d.cout) {
@@ -1087,24 +1077,11 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         case 128032: return launch_split<128, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 128064: return launch_split<128, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
 #endif
-        case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 6, FMT>(d, stream);
+        case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 8, FMT, 3>(d, stream);
         default: return hipErrorInvalidValue;
         }
     }
     constexpr int KG = 1, RG = 6;
-    if constexpr (BIG) {
-        if (epoch == 3) {   // (tuning aid) two terms: one barrier per 3 taps, ring of 8
-            switch (d.cin * 1000 + d.cout) {
-#ifndef W2XC_SPLIT_DEV
-            case 32064:  return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
-            case 64064:  return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
-            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
-#endif
-            case 128128: return launch_split<128, 128, 4, 2, 4, 2, T, OT, KG, 8, FMT, 3>(d, stream);
-            default: break;
-            }
-        }
-    }
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                     CIN  COUT  MB NB WM WN
