@@ -46,9 +46,15 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             q_.push_back(j);
+            pending_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         work_on(*j);
+        for (int spin = 0; spin < 20000 && j->done.load(std::memory_order_acquire) != j->parts; spin++) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
         std::unique_lock<std::mutex> lk(mu_);
         done_cv_.wait(lk, [&] { return j->done.load() == j->parts; });
     }
@@ -96,12 +102,20 @@ private:
     {
         for (;;) {
             std::shared_ptr<Job> j;
+            // jobs arrive in bursts (one per staged chunk, ~100 us apart while a plane streams through the rings): poll for
+            // a short while before sleeping, a condition-variable wake-up costs more than the copy of a 256 KiB part
+            for (int spin = 0; spin < 20000 && pending_.load(std::memory_order_acquire) == 0; spin++) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return !q_.empty(); });
                 j = q_.front();
                 if (j->next.load() >= j->parts) {   // fully handed out: retire it from the queue
                     q_.pop_front();
+                    pending_.fetch_sub(1, std::memory_order_release);
                     continue;
                 }
             }
@@ -109,6 +123,7 @@ private:
         }
     }
 
+    std::atomic<int> pending_{0};   // jobs in the queue (lock-free peek for the workers' polling phase)
     std::mutex mu_;
     std::condition_variable cv_, done_cv_;
     std::deque<std::shared_ptr<Job>> q_;
