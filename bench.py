@@ -159,7 +159,7 @@ def main():
                     help="skip the informational legs after the timed region (other precisions, the 8192x8192 plane at N=1, the weak figure at N>1)")
     ap.add_argument("--no-host", action="store_true", help="skip the host->host leg")
     ap.add_argument("--host-steps", type=int, default=0, help="host->host calls to time (default: max(5, steps))")
-    ap.add_argument("--jobs", type=int, default=0, help="modelUtility nJob = host staging threads of the host->host path (default: min(16, cores / 2 / ranks))")
+    ap.add_argument("--jobs", type=int, default=0, help="modelUtility nJob = host staging threads of the host->host path (default: the reference's 4; measured 4 ~ 8 > 16 > 32)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--band-rows", type=int, default=0)
     ap.add_argument("--precision", default="fp32", choices=PRECISIONS,
@@ -205,7 +205,7 @@ def main():
     layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
     ms = w2xc._ModelSet.from_layers(layers)
     n_layers = ms.n_layers
-    njobs = args.jobs if args.jobs > 0 else max(1, min(16, (os.cpu_count() or 4) // (2 * world)))
+    njobs = args.jobs if args.jobs > 0 else lib.w2xc_get_jobs()   # the reference's default: 4 (modelHandler.hpp:99, the CLI's -j)
     lib.w2xc_set_jobs(njobs)
 
     workload = args.workload

@@ -728,31 +728,6 @@ def test_fused_last_layer_vs_unfused(gpu, tmp_path):
     assert np.abs(a[:-3] - b[:-3]).max() <= 1e-4 * scale            # BF16X2 bound; FP16X2 is ~1e-6
 
 
-def test_bf16_first_generation_kernels_still_work(gpu, tmp_path):
-    """W2XC_PRECISION_BF16 runs through conv3x3_split with one term by default; W2XC_BF16_PIPE=v1 keeps the
-    first-generation path (conv3x3_first<bf16 out> / conv3x3_mfma_bf16 / conv3x3_last<bf16 in>).  Both must meet the
-    bf16 accuracy statement against the fp32 oracle, and the kernel names tell which one ran."""
-    import subprocess, sys
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from tools import gen_model; from oracle import oracle as orc\n"
-        "w = g.load_package(); layers = gen_model.synth_layers(seed=102); ms = w._ModelSet.from_layers(layers)\n"
-        "x = np.random.default_rng(3).random((96, 128), dtype=np.float32)\n"
-        "o = w.make_opts(precision=w.PRECISION_BF16)\n"
-        "got = ms.convert(x, opts=o); want = orc.Oracle(layers).convert(x)\n"
-        "print('ERR', float(np.abs(got - want).max()), float(np.mean((got.astype(np.float64) - want) ** 2)), ms.kernel_name(3, o))\n" % ROOT)
-    seen = {}
-    for pipe in ("v1", "split"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, W2XC_BF16_PIPE=pipe), capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        line = [l for l in r.stdout.splitlines() if l.startswith("ERR")][0].split()
-        err, mse, name = float(line[1]), float(line[2]), line[3]
-        seen[pipe] = name
-        assert err <= 2e-2 and 10 * np.log10(1.0 / mse) >= 45.0, (pipe, err, mse)
-    assert seen == {"v1": "conv3x3_mfma_bf16", "split": "conv3x3_split"}, seen
-
-
 def test_fused_first_two_layers_vs_unfused(gpu, tmp_path):
     """the 16-bit modes run layers 1 (1 -> 32) and 2 (32 -> C) as ONE kernel (conv3x3_first2_split: layer 1's terms stay in
     LDS).  It uses the same arithmetic in the same order as conv3x3_first_split + conv3x3_split, so with

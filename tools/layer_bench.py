@@ -12,10 +12,10 @@ ap.add_argument("--cin", type=int, default=128); ap.add_argument("--cout", type=
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--zero", action="store_true", help="all-zero input plane (constant activations: data-dependent power check)")
-ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16x2, 3 bf16x3 (split modes time a T->T mid layer: model 1->cin->cout->cout->1)")
+ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16x2, 3 bf16x3, 4 fp16x2 (16-bit modes time a T->T mid layer: model 1->cin->cout->cout->1)")
 a = ap.parse_args()
 w2xc = graft.load_package()
-topo = [1, a.cin, a.cout, 1] if a.precision < 2 else [1, a.cin, a.cout, a.cout, 1]
+topo = [1, a.cin, a.cout, 1] if a.precision < 1 else [1, a.cin, a.cout, a.cout, 1]
 ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(topo, 7))
 x = torch.zeros(a.h, a.w, device="cuda") if a.zero else torch.rand(a.h, a.w, device="cuda"); y = torch.empty_like(x)
 o = w2xc.make_opts(device=0, profile=1, precision=a.precision)

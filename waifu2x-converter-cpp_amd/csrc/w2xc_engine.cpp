@@ -77,7 +77,6 @@ struct DevLayer {
     W2xcKernelKind fast = W2XC_K_DIRECT;
     float *w_fast = nullptr;
     float *w_direct = nullptr;
-    float *w_bf16 = nullptr;    // conv3x3_mfma_bf16 image, packed on first use of W2XC_PRECISION_BF16
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[3] = {nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms
@@ -155,6 +154,8 @@ struct DevCtx {
     FilterCache fc;
     float *aux = nullptr;       // N2: Y/U/V planes of the image pipeline
     size_t aux_floats = 0;
+    unsigned char *img_io = nullptr;   // N2, host entry points: device copies of the uint8 image in / out (grow-only)
+    size_t img_io_bytes = 0;
     std::vector<ProfEvent> pending, pool;
     std::vector<double> layer_ms;
     std::vector<int> layer_launches;
@@ -168,7 +169,6 @@ struct DevCtx {
         for (auto &l : layers) {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
-            if (l.w_bf16) hipFree(l.w_bf16);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
             for (float *p : l.w_last_fused)
@@ -185,6 +185,7 @@ struct DevCtx {
         for (int i = 0; i < 2; i++)
             if (ws[i]) hipFree(ws[i]);
         if (aux) hipFree(aux);
+        if (img_io) hipFree(img_io);
         for (auto &e : pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto &e : pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         hipSetDevice(prev);
@@ -250,11 +251,7 @@ w2xc_opts resolve_opts(const w2xc_opts *o)
 // 16-bit terms per activation value between the layers of the split pipeline, w2xc_split.hip (0 = not that pipeline)
 int split_terms(const w2xc_opts &o)
 {
-    if (o.precision == W2XC_PRECISION_BF16) {   // plain bf16 = the same pipeline with ONE term; W2XC_BF16_PIPE=v1 selects
-        static int v = -1;                      // the first-generation kernels (conv3x3_mfma_bf16, NHWC bf16 activations)
-        if (v < 0) { const char *e = getenv("W2XC_BF16_PIPE"); v = (e && !strcmp(e, "v1")) ? 0 : 1; }
-        return v;
-    }
+    if (o.precision == W2XC_PRECISION_BF16) return 1;   // plain bf16 = the same pipeline with ONE term
     return (o.precision == W2XC_PRECISION_BF16X2 || o.precision == W2XC_PRECISION_FP16X2) ? 2 : o.precision == W2XC_PRECISION_BF16X3 ? 3 : 0;
 }
 int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 ? 1 : 0; }
@@ -276,14 +273,6 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
             return (n > 1 && w2xc_pick_kernel(m->layers[1].nin, m->layers[1].nout) == W2XC_K_MFMA) ? W2XC_K_FIRST_SPLIT : W2XC_K_FIRST;
         if (k == W2XC_K_LAST && l == n - 1 && l > 0) return fuse_last(m, o) ? W2XC_K_LAST_GATHER : W2XC_K_LAST;
         return W2XC_K_DIRECT;   // run_rows rejects this
-    }
-    if (o.precision == W2XC_PRECISION_BF16) {
-        // bf16 activations live only BETWEEN layers: the first layer reads the caller's fp32 plane, the
-        // last one writes it; anything else (or a shape without an MFMA kernel) is unsupported
-        if (l == 0 && k == W2XC_K_FIRST && m->layers[l].nin == 1) return W2XC_K_FIRST_BF16OUT;
-        if (l == n - 1 && k == W2XC_K_LAST && m->layers[l].nout == 1) return W2XC_K_LAST_BF16IN;
-        if (l > 0 && l < n - 1 && k == W2XC_K_MFMA) return W2XC_K_MFMA_BF16;
-        return W2XC_K_DIRECT;   // run_rows rejects this for bf16
     }
     return k;
 }
@@ -402,12 +391,6 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     DevLayer &dl = c->layers[l];
     d.cin = m->layers[l].nin;
     d.cout = m->layers[l].nout;
-    if (kind == W2XC_K_MFMA_BF16 && !dl.w_bf16) {
-        std::vector<float> pk(w2xc_packed_weight_floats(kind, d.cin, d.cout));
-        w2xc_pack_weights(kind, d.cin, d.cout, m->layers[l].w.data(), pk.data());
-        int rc = upload(pk, &dl.w_bf16);
-        if (rc) return rc;
-    }
     if (kind == W2XC_K_FUSED_AWAY) return W2XC_OK;   // computed by the next layer's W2XC_K_FIRST2_SPLIT launch
     if (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) {
         if (d.terms < 1 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
@@ -440,7 +423,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     } else if (kind == W2XC_K_LAST_GATHER) {
         d.wpk = nullptr;
     } else {
-        d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : kind == W2XC_K_MFMA_BF16 ? dl.w_bf16 : dl.w_fast;
+        d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
     d.bias = dl.bias;
     ProfEvent ev;
@@ -487,15 +470,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         if (m->layers[l].nin != m->layers[l - 1].nout)
             return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
     const int T = split_terms(o);
-    const bool bf16 = (o.precision == W2XC_PRECISION_BF16) && T == 0;
-    if (o.precision != W2XC_PRECISION_FP32 && !bf16 && T == 0) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
-    if (bf16) {
-        if (n < 2 || m->layers[n - 1].nout != 1) return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16 needs >= 2 layers ending in one plane");
-        for (int l = 0; l < n; l++)
-            if (layer_kind(m, l, o) == W2XC_K_DIRECT)
-                return fail(W2XC_ERR_UNSUPPORTED, "W2XC_PRECISION_BF16: layer %d (%d->%d) has no bf16 kernel (1->{32,64,128}, {32,64,128}->{32,64,128}, ->1 only)",
-                            l + 1, m->layers[l].nin, m->layers[l].nout);
-    }
+    if (o.precision != W2XC_PRECISION_FP32 && T == 0) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
     if (T > 0)
         for (int l = 0; l < n; l++)
             if (layer_kind(m, l, o) == W2XC_K_DIRECT)
@@ -503,7 +478,6 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                             l + 1, m->layers[l].nin, m->layers[l].nout);
     // bytes per activation element of layer k's output (k = 1..n) in the workspace
     auto out_bpe = [&](int k) -> size_t {
-        if (bf16) return 2;
         const int ot = out_terms_of(m, k - 1, o);
         return (ot >= 1 && ot <= 3) ? 2 * (size_t)ot : 4;
     };
@@ -512,7 +486,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     // output (conv3x3_last / conv3x3_direct); otherwise it goes through the NHWC workspace + a repack
     const W2xcKernelKind last_kind = layer_kind(m, n - 1, o);
     const bool last_direct = (m->layers[n - 1].nout == 1 || all_out) &&
-                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_GATHER || last_kind == W2XC_K_LAST_BF16IN || last_kind == W2XC_K_DIRECT ||
+                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_GATHER || last_kind == W2XC_K_DIRECT ||
                               (m->layers[n - 1].nout == 1 && last_kind != W2XC_K_MFMA && last_kind != W2XC_K_FIRST));
     // BYTES per band for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
     auto ws_need = [&](int rows, size_t need[2]) {
@@ -626,7 +600,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 if (rc) return rc;
             }
             const bool chunked = hk && k == n && direct_out && hk->out_chunk_rows > 0 && d.out_h > std::max(hk->out_chunk_min, 8) &&
-                                 (kind == W2XC_K_LAST || kind == W2XC_K_LAST_GATHER || kind == W2XC_K_LAST_BF16IN || kind == W2XC_K_DIRECT);
+                                 (kind == W2XC_K_LAST || kind == W2XC_K_LAST_GATHER || kind == W2XC_K_DIRECT);
             if (chunked) {
                 // the last layer in row chunks: chunk j's rows leave for the host while chunk j+1 is computed
                 for (int c0 = 0, cr = 0; c0 < d.out_h; c0 += cr) {
@@ -1650,22 +1624,29 @@ try {
     if (!guard.ok) return fail(W2XC_ERR_HIP, "cannot select HIP device %d", dev);
     int W, H;
     final_size(w, h, iterations, shrink_ratio, &W, &H);
-    unsigned char *d_in = nullptr, *d_out = nullptr;
-    auto body = [&]() -> int {
-        HIP_TRY(hipMalloc((void **)&d_in, (size_t)w * 3 * h));
-        HIP_TRY(hipMalloc((void **)&d_out, (size_t)W * 3 * H));
-        HIP_TRY(hipMemcpy2D(d_in, (size_t)w * 3, in, in_stride_bytes, (size_t)w * 3, h, hipMemcpyHostToDevice));
-        int r = process_image_locked(noise_model, scale_model, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, shrink_ratio,
-                                     nullptr, o, dev);
-        if (r) return r;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy2D(out, out_stride_bytes, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost));
-        return W2XC_OK;
-    };
-    rc = body();
-    hipFree(d_in);
-    hipFree(d_out);
-    return rc;
+    // contexts of the (up to two) models, locked for the whole call: the device copies of the image live in the owning context
+    // (the scale model's when present) and are kept between calls -- no hipMalloc / hipFree per image
+    DevCtx *cn = nullptr, *cs = nullptr;
+    if (noise_model && (rc = get_ctx(noise_model, dev, &cn))) return rc;
+    if (scale_model && (rc = get_ctx(scale_model, dev, &cs))) return rc;
+    std::unique_lock<std::mutex> l1, l2;
+    if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
+    if (cs && cs != cn) l2 = std::unique_lock<std::mutex>(cs->mu);
+    DevCtx *c = cs ? cs : cn;
+    const size_t in_bytes = ((size_t)w * 3 * h + 255) & ~(size_t)255, out_bytes = (size_t)W * 3 * H;
+    if (c->img_io_bytes < in_bytes + out_bytes) {
+        if (c->img_io) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->img_io)); c->img_io = nullptr; c->img_io_bytes = 0; }
+        if (hipMalloc((void **)&c->img_io, in_bytes + out_bytes) != hipSuccess)
+            return fail(W2XC_ERR_NOMEM, "hipMalloc(%zu MiB) for the image failed", (in_bytes + out_bytes) >> 20);
+        c->img_io_bytes = in_bytes + out_bytes;
+    }
+    unsigned char *d_in = c->img_io, *d_out = c->img_io + in_bytes;
+    HIP_TRY(hipMemcpy2D(d_in, (size_t)w * 3, in, in_stride_bytes, (size_t)w * 3, h, hipMemcpyHostToDevice));
+    rc = process_image_device(noise_model, cn, scale_model, cs, d_in, (size_t)w * 3, w, h, d_out, (size_t)W * 3, iterations, shrink_ratio, nullptr, o);
+    if (rc) { hipDeviceSynchronize(); return rc; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(out, out_stride_bytes, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost));
+    return W2XC_OK;
 } W2XC_CATCH_ALL
 
 int w2xc_process_image_u8(w2xc_model *noise_model, w2xc_model *scale_model, const unsigned char *in, size_t in_stride_bytes, int w, int h,

@@ -49,10 +49,6 @@ enum W2xcKernelKind {
     W2XC_K_MFMA = 1,     // cin, cout in {32,64,128}; NHWC in/out; fp32 MFMA implicit GEMM
     W2XC_K_FIRST = 2,    // cin <= 3 -> cout multiple of 32: planar in, NHWC out, fp32 MFMA (K = 9*cin)
     W2XC_K_LAST = 3,     // cin multiple of 32 -> cout <= 3: NHWC in, planar out, taps-as-N fp32 MFMA
-    // W2XC_PRECISION_BF16: activations between layers are NHWC bf16 (strides still in ELEMENTS), fp32 accumulate
-    W2XC_K_MFMA_BF16 = 4,      // cin, cout in {32,64,128}: bf16 in/out, bf16 weights, v_mfma_f32_32x32x16_bf16
-    W2XC_K_FIRST_BF16OUT = 5,  // W2XC_K_FIRST (fp32 planar in, fp32 weights) storing bf16 NHWC
-    W2XC_K_LAST_BF16IN = 6,    // W2XC_K_LAST reading bf16 NHWC (widened to fp32 exactly), fp32 planar out
     // W2XC_PRECISION_BF16X2 / BF16X3 (and BF16 through the same pipeline): fp32 values carried as d.terms bf16 terms
     W2XC_K_MID_SPLIT = 7,      // cin, cout in {32,64,128}: term planes in, term planes (or fp32 when out_terms = 0) out
     W2XC_K_FIRST_SPLIT = 8,    // W2XC_K_FIRST storing d.out_terms term planes

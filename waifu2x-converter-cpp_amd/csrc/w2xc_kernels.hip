@@ -6,13 +6,13 @@
 //   conv3x3_direct      any (cin, cout), any strides.  VALU, one thread per output pixel and 8
 //                       output planes; sums in the REFERENCE'S order with unfused mul/add, so it
 //                       is bit-exact against the CPU oracle.  Fallback + on-GPU cross-check.
-//   conv3x3_mfma        cin, cout in {32,64,128}.  NHWC fp32 activations; the (rows+2) x 34 pixel
-//                       halo tile of a 32-channel slice is staged in LDS (pixel stride 36 floats:
-//                       conflict-free ds_read_b128), the 3x3xCinxCout contraction is an implicit
-//                       GEMM on v_mfma_f32_32x32x2_f32 (M = 32 pixels of one row, N = 32 output
-//                       planes, K = (tap, cin)), weights stream from L2 in fragment order
-//                       (one coalesced dwordx4 per lane per 4 MFMAs), bias + LeakyReLU fused
-//                       into the epilogue, NHWC stores in 128-byte runs.
+//   conv3x3_mfma2       cin, cout in {32,64,128}.  NHWC fp32 activations; persistent workgroups (one per CU); the
+//                       10 x 34 pixel halo tile of a 32-channel slice and the weights of one (slice, tap) stage reach
+//                       LDS by LDS-DMA (XOR-swizzled: conflict-free ds_read_b128), the 3x3xCinxCout contraction is an
+//                       implicit GEMM on v_mfma_f32_32x32x2_f32 (M = 32 pixels of one row, N = 32 output planes,
+//                       K = (tap, cin)), bias + LeakyReLU fused into the epilogue, NHWC stores in 128-byte runs.
+//                       (The first-generation kernel it replaced -- register-staged tiles, weights from L2 -- was
+//                       removed in round 2; its history is in DESIGN.md 3.)
 //   conv3x3_first       cin <= 3 (layer 1): planar input, clamp-to-edge folded into the LDS fill
 //                       (this is cv::copyMakeBorder, convertRoutine.cpp:35), K = 9*cin on the same
 //                       32x32x2 MFMA, NHWC output.  HBM-write bound.
@@ -78,140 +78,6 @@ __global__ void __launch_bounds__(256) conv3x3_direct(W2xcConvDesc d, int cout_p
             const float v = __fadd_rn(acc[k], d.bias[og + k]);                           // :147
             const float pos = v > 0.0f ? v : 0.0f, neg = v < 0.0f ? v : 0.0f;            // :150-151
             op[(long long)(og + k) * d.out_cs] = __fadd_rn(__fmul_rn(neg, 0.1f), pos);   // :152
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv3x3_mfma: fp32 MFMA implicit GEMM.
-//   Workgroup = WM x WN waves; output tile = (MB*WM) rows x 32 pixels x COUT planes.
-//   Wave (wm, wn) owns MB row-blocks (M = 32 pixels of one image row) x NB plane-blocks (N = 32).
-//   K loop: cin slices of CC=32 staged in LDS; per slice 9 taps x 4 groups of 8 channels; per
-//   group one ds_read_b128 per row-block (A) and one global dwordx4 per plane-block (B) feed
-//   4 MFMA k-steps: lane (i = lane&31, kk = lane>>5) holds channels 4*kk..4*kk+3 of the group,
-//   MFMA j contracts channels {j, 4+j}.
-//   Packed weights: wpk[tap][cin/8][cout/32][lane][4], element j of lane (kk, n) =
-//   W[o = 32*nb + n][i = 8*c8 + 4*kk + j][tap].
-// ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-__global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma(W2xcConvDesc d, int tiles_x, int ntiles)
-{
-    constexpr int CC = 32;                 // channels per LDS slice
-    constexpr int ROWS = MB * WM;
-    constexpr int HW = 34, HH = ROWS + 2;  // halo tile
-    constexpr int CS = CC + 4;             // LDS pixel stride (floats): 144 B, odd multiple of 16 B
-    constexpr int NT = WM * WN * 64;
-    constexpr int NBT = COUT / 32;
-    static_assert(NB * WN == NBT, "plane blocks must tile COUT");
-    static_assert(CIN % CC == 0, "cin must be a multiple of 32");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
-
-    const float *a_lane = lds + ((wm * MB) * HW + (lane & 31)) * CS + (lane >> 5) * 4;
-    const f32x4 *b_lane = reinterpret_cast<const f32x4 *>(d.wpk) + (wn * NB) * 64 + lane;
-
-    // ---- halo-slice staging, split in two (issue early / write late): the global loads of slice
-    //      c+1 are issued before the MFMA loop of slice c and land in registers while the matrix
-    //      cores work; after the loop they are written to LDS between two barriers.  8 lanes move
-    //      one pixel's 128 B.  Offsets are in float4 units (16 B) so 32 bits cover 64 GiB. ----
-    constexpr int Q = CC / 4;
-    constexpr int NFILL = HH * HW * Q;
-    constexpr int PF = (NFILL + NT - 1) / NT;
-    unsigned goff[PF];
-    f32x4 pf[PF];
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-        int idx = threadIdx.x + u * NT;
-        idx = idx < NFILL ? idx : NFILL - 1;
-        const int p = idx / Q, q = idx - p * Q;
-        const int py = p / HW, px = p - py * HW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
-        goff[u] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 2) + q;
-    }
-    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
-#pragma unroll
-    for (int u = 0; u < PF; u++) pf[u] = in4[goff[u]];
-
-    for (int c0 = 0; c0 < CIN; c0 += CC) {
-        if (c0) __syncthreads();   // every wave is done reading the previous slice
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int idx = threadIdx.x + u * NT;
-            if (idx < NFILL) *reinterpret_cast<f32x4 *>(lds + (idx / Q) * CS + (idx % Q) * 4) = pf[u];
-        }
-        __syncthreads();
-        if (c0 + CC < CIN) {
-#pragma unroll
-            for (int u = 0; u < PF; u++) pf[u] = in4[goff[u] + (c0 + CC) / 4];
-        }
-
-        const f32x4 *bp = b_lane + (long long)(c0 / 8) * NBT * 64;
-        f32x4 a_cur[MB], b_cur[NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) a_cur[mb] = *reinterpret_cast<const f32x4 *>(a_lane + (mb * HW) * CS);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) b_cur[nb] = bp[nb * 64];
-#pragma unroll
-        for (int step = 0; step < 9 * (CC / 8); step++) {
-            f32x4 a_nxt[MB], b_nxt[NB];
-            if (step + 1 < 9 * (CC / 8)) {
-                const int tap = (step + 1) / (CC / 8), c8 = (step + 1) % (CC / 8);
-                const int ty = tap / 3, tx = tap % 3;
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-                    a_nxt[mb] = *reinterpret_cast<const f32x4 *>(a_lane + ((mb + ty) * HW + tx) * CS + c8 * 8);
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    b_nxt[nb] = bp[((long long)(tap * (CIN / 8) + c8) * NBT + nb) * 64];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb][j], b_cur[nb][j],
-                                                                          acc[mb][nb], 0, 0, 0);
-            if (step + 1 < 9 * (CC / 8)) {
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++) a_cur[mb] = a_nxt[mb];
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) b_cur[nb] = b_nxt[nb];
-            }
-        }
-    }
-
-    // ---- epilogue: bias + LeakyReLU, NHWC stores.  C/D map of 32x32 MFMA: column = lane&31
-    //      (output plane), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel in the row-block). ----
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-        const int y = oy0 + wm * MB + mb;
-        if (y >= d.out_h) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int n = (wn * NB + nb) * 32 + (lane & 31);
-            const float bv = d.bias[n];
-            float *orow = d.out + (long long)y * d.out_rs + n;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (x < d.out_w) orow[(long long)x * COUT] = leaky(acc[mb][nb][r] + bv);
-            }
         }
     }
 }
@@ -505,132 +371,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3x3_mfma_bf16: bf16 activations and weights, fp32 accumulate (W2XC_PRECISION_BF16, layers 2..n-1).
-//   Same implicit GEMM as conv3x3_mfma on v_mfma_f32_32x32x16_bf16 (K = 16 channels per instruction,
-//   32 cycles): lane (i = lane&31, kk = lane>>5) supplies channels 16*c16 + 8*kk .. +7 = one 16-byte chunk.
-//   LDS: (rows+2) x 34 pixels x 32 channels, pixel stride 80 B (64 + 16: odd multiple of 16 B, so the
-//   ds_read_b128 of 32 consecutive pixels is conflict-free).  Weights wpk16[tap][cin/16][cout/32][lane][8]
-//   stream from L2 in fragment order.  Epilogue: bias + LeakyReLU in fp32, round-to-nearest-even to bf16.
-// ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-__global__ void __launch_bounds__(WM *WN * 64) conv3x3_mfma_bf16(W2xcConvDesc d, int tiles_x, int ntiles)
-{
-    constexpr int ROWS = MB * WM, HW = 34, HH = ROWS + 2;
-    constexpr int PSB = 80;                 // LDS pixel stride in bytes
-    constexpr int NT = WM * WN * 64, NBT = COUT / 32;
-    static_assert(NB * WN == NBT && CIN % 32 == 0, "shape");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    char *ldsb = reinterpret_cast<char *>(lds);
-
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
-
-    const char *a_lane = ldsb + ((wm * MB) * HW + (lane & 31)) * PSB + (lane >> 5) * 16;
-    const u32x4 *b_lane = reinterpret_cast<const u32x4 *>(d.wpk) + (wn * NB) * 64 + lane;
-
-    // halo slice staging through registers (issue early / write late), 4 lanes move one pixel's 64 B
-    constexpr int Q = 4, NFILL = HH * HW * Q, PF = (NFILL + NT - 1) / NT;
-    unsigned goff[PF];
-    u32x4 pf[PF];
-    const u32x4 *in4 = reinterpret_cast<const u32x4 *>(d.in);
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-        int idx = threadIdx.x + u * NT;
-        idx = idx < NFILL ? idx : NFILL - 1;
-        const int p = idx / Q, q = idx - p * Q;
-        const int py = p / HW, px = p - py * HW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
-        goff[u] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 3) + q;   // 16-byte units = 8 bf16
-    }
-#pragma unroll
-    for (int u = 0; u < PF; u++) pf[u] = in4[goff[u]];
-
-    for (int c0 = 0; c0 < CIN; c0 += 32) {
-        if (c0) __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int idx = threadIdx.x + u * NT;
-            if (idx < NFILL) *reinterpret_cast<u32x4 *>(ldsb + (idx / Q) * PSB + (idx % Q) * 16) = pf[u];
-        }
-        __syncthreads();
-        if (c0 + 32 < CIN) {
-#pragma unroll
-            for (int u = 0; u < PF; u++) pf[u] = in4[goff[u] + (c0 + 32) / 8];
-        }
-        const u32x4 *bp = b_lane + (long long)(c0 / 16) * NBT * 64;
-#pragma unroll
-        for (int step = 0; step < 18; step++) {
-            const int tap = step >> 1, c16 = step & 1;
-            const int ty = tap / 3, tx = tap % 3;
-            bf16x8 a[MB], b[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; mb++)
-                a[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_lane + ((mb + ty) * HW + tx) * PSB + c16 * 32));
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                b[nb] = __builtin_bit_cast(bf16x8, bp[((long long)(tap * (CIN / 16) + c16) * NBT + nb) * 64]);
-#pragma unroll
-            for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: bias + LeakyReLU in fp32, RNE to bf16, then a per-wave transpose through LDS so that
-    //      global stores are 16 B per lane in full 128-byte runs (the MFMA C/D layout has ONE channel
-    //      per lane, i.e. 2-byte scattered stores otherwise -- they dominated the first version).
-    //      Staging: [MB rows x 32 pixels][NB*32 channels] bf16, pixel stride NB*64 + 16 bytes. ----
-    __syncthreads();                                 // all waves are done with the A tile: reuse the LDS
-    constexpr int EPS = NB * 64 + 16;                // bytes per staged pixel
-    char *stage = ldsb + wave * (MB * 32 * EPS);
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const float bv = d.bias[(wn * NB + nb) * 32 + (lane & 31)];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int px = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                *reinterpret_cast<bf16_t *>(stage + (mb * 32 + px) * EPS + (nb * 32 + (lane & 31)) * 2) = f2bf(leaky(acc[mb][nb][r] + bv));
-            }
-        }
-    // same wave wrote and reads: program order + the compiler's lgkmcnt wait suffice
-    bf16_t *out16 = reinterpret_cast<bf16_t *>(d.out);
-    constexpr int CPP = NB * 4;                      // 16-byte chunks per staged pixel
-    constexpr int NCH = MB * 32 * CPP;               // chunks in this wave's tile
-#pragma unroll
-    for (int it = 0; it < NCH / 64; it++) {
-        const int ch = it * 64 + lane;
-        const int sp = ch / CPP, q = ch - sp * CPP;  // staged pixel, chunk
-        const int mb = sp >> 5, px = sp & 31;
-        const int y = oy0 + wm * MB + mb, x = ox0 + px;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + sp * EPS + q * 16);
-        if (y < d.out_h && x < d.out_w)
-            *reinterpret_cast<u32x4 *>(out16 + (long long)y * d.out_rs + (long long)x * COUT + (wn * NB) * 32 + q * 8) = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // conv3x3_first: cin <= 3, planar input, cout = 32*NBT planes, NHWC output.
 //   K = 9*CIN (k = c*9 + tap), padded to 2*S; lane (i, kk) feeds k = 2*s + kk of MFMA step s.
 //   Packed weights: wpk[nb][s][lane] = W[32*nb + (lane&31)][c][tap] for k = 2*s + (lane>>5) < K, else 0.
 //   Workgroup = 4 waves, tile = 8 rows x 32 pixels; wave w owns rows 2w, 2w+1.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int NBT, typename OutT = float>
+template <int CIN, int NBT>
 __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2;
@@ -691,20 +437,13 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
         for (int mb = 0; mb < MB; mb++) {
             const int y = oy0 + wave * MB + mb;
             if (y < d.out_h && x < d.out_w) {
-                OutT *op = reinterpret_cast<OutT *>(d.out) + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * kk;
+                float *op = d.out + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * kk;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e]);
-                    if (sizeof(OutT) == 4) {
-                        *reinterpret_cast<f32x4 *>(op + 8 * q) = v;
-                    } else {
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *reinterpret_cast<uint2 *>(op + 8 * q) = pk;
-                    }
+                    *reinterpret_cast<f32x4 *>(op + 8 * q) = v;
                 }
             }
         }
@@ -722,7 +461,7 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 //   Then out[p][o] = leaky(bias[o] + sum_tap G[p + tap][tap*COUT + o]) via LDS.
 //   Workgroup = 4 waves, tile = ROWS x 32 output pixels.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, typename InT = float>
+template <int CIN, int COUT>
 __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x, int ntiles)
 {
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
@@ -754,21 +493,9 @@ __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x,
         const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
         const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
         f32x4 av[S4];
-        if (sizeof(InT) == 4) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(d.in + (long long)gy * d.in_rs + (long long)gx * CIN) + kk;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(d.in + (long long)gy * d.in_rs + (long long)gx * CIN) + kk;
 #pragma unroll
-            for (int s4 = 0; s4 < S4; s4++) av[s4] = src[s4 * 4];
-        } else {   // bf16 activations: 4 channels = 8 bytes, widened exactly to fp32
-            const uint2 *src = reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(d.in) + (long long)gy * d.in_rs + (long long)gx * CIN) + kk;
-#pragma unroll
-            for (int s4 = 0; s4 < S4; s4++) {
-                const uint2 u = src[s4 * 4];
-                av[s4][0] = __uint_as_float(u.x << 16);
-                av[s4][1] = __uint_as_float(u.x & 0xFFFF0000u);
-                av[s4][2] = __uint_as_float(u.y << 16);
-                av[s4][3] = __uint_as_float(u.y & 0xFFFF0000u);
-            }
-        }
+        for (int s4 = 0; s4 < S4; s4++) av[s4] = src[s4 * 4];
         f32x4 acc[NB16];
 #pragma unroll
         for (int nb = 0; nb < NB16; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -840,9 +567,6 @@ const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout)
     case W2XC_K_MFMA: return "conv3x3_mfma";
     case W2XC_K_FIRST: return "conv3x3_first";
     case W2XC_K_LAST: return "conv3x3_last";
-    case W2XC_K_MFMA_BF16: return "conv3x3_mfma_bf16";
-    case W2XC_K_FIRST_BF16OUT: return "conv3x3_first<bf16 out>";
-    case W2XC_K_LAST_BF16IN: return "conv3x3_last<bf16 in>";
     case W2XC_K_MID_SPLIT: return "conv3x3_split";
     case W2XC_K_FIRST_SPLIT: return "conv3x3_first_split";
     case W2XC_K_LAST_GATHER: return "conv3x3_last_gather";
@@ -858,9 +582,8 @@ size_t w2xc_packed_weight_floats(W2xcKernelKind kind, int cin, int cout)
 {
     switch (kind) {
     case W2XC_K_MFMA: return (size_t)9 * cin * cout;
-    case W2XC_K_FIRST: case W2XC_K_FIRST_BF16OUT: case W2XC_K_FIRST_SPLIT: return (size_t)(cout / 32) * ((9 * cin + 1) / 2) * 64;
-    case W2XC_K_LAST: case W2XC_K_LAST_BF16IN: return (size_t)(cin / 16) * 4 * ((9 * cout + 15) / 16) * 64;
-    case W2XC_K_MFMA_BF16: return ((size_t)9 * cin * cout + 1) / 2;   // bf16 pairs per float slot
+    case W2XC_K_FIRST: case W2XC_K_FIRST_SPLIT: return (size_t)(cout / 32) * ((9 * cin + 1) / 2) * 64;
+    case W2XC_K_LAST: return (size_t)(cin / 16) * 4 * ((9 * cout + 15) / 16) * 64;
     default: return (size_t)cin * 9 * direct_cout_pad(cout);
     }
 }
@@ -869,26 +592,7 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 {
     auto W = [&](int o, int i, int tap) { return w[((size_t)o * cin + i) * 9 + tap]; };
     memset(dst, 0, w2xc_packed_weight_floats(kind, cin, cout) * sizeof(float));
-    if (kind == W2XC_K_FIRST_BF16OUT || kind == W2XC_K_FIRST_SPLIT) kind = W2XC_K_FIRST;
-    if (kind == W2XC_K_LAST_BF16IN) kind = W2XC_K_LAST;
-    if (kind == W2XC_K_MFMA_BF16) {
-        auto bf = [](float f) -> unsigned short {
-            unsigned u;
-            memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return (unsigned short)(u >> 16);
-        };
-        unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
-        const int nbt = cout / 32, c16n = cin / 16;
-        for (int tap = 0; tap < 9; tap++)
-            for (int c16 = 0; c16 < c16n; c16++)
-                for (int nb = 0; nb < nbt; nb++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int e = 0; e < 8; e++)
-                            d16[((((size_t)tap * c16n + c16) * nbt + nb) * 64 + lane) * 8 + e] =
-                                bf(W(nb * 32 + (lane & 31), c16 * 16 + (lane >> 5) * 8 + e, tap));
-        return;
-    }
+    if (kind == W2XC_K_FIRST_SPLIT) kind = W2XC_K_FIRST;
     if (kind == W2XC_K_MFMA) {
         const int nbt = cout / 32, c8n = cin / 8;
         for (int tap = 0; tap < 9; tap++)
@@ -926,18 +630,6 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 }
 
 template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-static hipError_t launch_mfma(const W2xcConvDesc &d, hipStream_t stream)
-{
-    constexpr int ROWS = MB * WM;
-    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + ROWS - 1) / ROWS;
-    const int ntiles = tiles_x * tiles_y;
-    const size_t lds_bytes = (size_t)(ROWS + 2) * 34 * 36 * sizeof(float);
-    hipLaunchKernelGGL((conv3x3_mfma<CIN, COUT, MB, NB, WM, WN>), dim3(ntiles), dim3(WM * WN * 64), lds_bytes, stream,
-                       d, tiles_x, ntiles);
-    return hipGetLastError();
-}
-
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
 static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
@@ -962,26 +654,12 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// W2XC_MFMA_V2 (tuning aid): unset = default tilings, 0 = force conv3x3_mfma (v1), 1 = conv3x3_mfma2 with 4 waves
+// W2XC_MFMA_V2 (tuning aid): unset = default tilings, 1 = conv3x3_mfma2 with 4 waves everywhere, 3 = 8 waves where possible
 static int mfma_v2_enabled()
 {
     static int v = -2;
     if (v == -2) { const char *e = getenv("W2XC_MFMA_V2"); v = e ? atoi(e) : -1; }
     return v;
-}
-
-template <int CIN, int COUT, int MB, int NB, int WM, int WN>
-static hipError_t launch_mfma_bf16(const W2xcConvDesc &d, hipStream_t stream)
-{
-    constexpr int ROWS = MB * WM;
-    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + ROWS - 1) / ROWS;
-    const int ntiles = tiles_x * tiles_y;
-    size_t lds_bytes = (size_t)(ROWS + 2) * 34 * 80;                      // A halo tile ...
-    const size_t stage_bytes = (size_t)WM * WN * MB * 32 * (NB * 64 + 16);  // ... reused by the store transpose
-    if (stage_bytes > lds_bytes) lds_bytes = stage_bytes;
-    hipLaunchKernelGGL((conv3x3_mfma_bf16<CIN, COUT, MB, NB, WM, WN>), dim3(ntiles), dim3(WM * WN * 64), lds_bytes, stream,
-                       d, tiles_x, ntiles);
-    return hipGetLastError();
 }
 
 template <typename KernelT>
@@ -996,76 +674,27 @@ static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    if (d.in_shift != 0 && kind != W2XC_K_FIRST && kind != W2XC_K_FIRST_BF16OUT && kind != W2XC_K_DIRECT) return hipErrorInvalidValue;
+    if (d.in_shift != 0 && kind != W2XC_K_FIRST && kind != W2XC_K_DIRECT) return hipErrorInvalidValue;
     if (kind == W2XC_K_MFMA) {
         if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
-        // conv3x3_mfma2 (LDS-DMA pipeline) unless W2XC_MFMA_V2=0 (conv3x3_mfma, the first-generation
-        // kernel, kept as a fallback).  Measured inside the 7-layer model (round 2, same box, same run): 8 waves (two per
-        // SIMD: the partner's MFMAs cover this wave's non-MFMA issue slots) win wherever the output has >= 64 planes
-        // (32->64 -1.8 %, 64->64 -2.5 %, 64->128 -2.9 %, 128->128 -2.9 %); 32->32 has one plane block, so its 8 waves would
-        // split rows only (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
+        // Measured inside the 7-layer model (round 2, same box, same run): 8 waves (two per SIMD: the partner's MFMAs cover
+        // this wave's non-MFMA issue slots) win wherever the output has >= 64 planes (32->64 -1.8 %, 64->64 -2.5 %,
+        // 64->128 -2.9 %, 128->128 -2.9 %); 32->32 has one plane block, so its 8 waves would split rows only
+        // (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
         const int v2 = mfma_v2_enabled();
-        if (v2 != 0) {
-            const bool w8 = (v2 == 3) || (v2 < 0 && d.cout >= 64);
-            switch (key) {
-            //                                  CIN  COUT  MB NB WM WN
-            case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
-            case 32064:  return w8 ? launch_mfma2<32, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
-            case 32128:  return w8 ? launch_mfma2<32, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
-            case 64032:  return launch_mfma2<64, 32, 2, 1, 4, 1>(d, stream);
-            case 64064:  return w8 ? launch_mfma2<64, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<64, 64, 2, 2, 4, 1>(d, stream);
-            case 64128:  return w8 ? launch_mfma2<64, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<64, 128, 4, 2, 2, 2>(d, stream);
-            case 128032: return launch_mfma2<128, 32, 2, 1, 4, 1>(d, stream);
-            case 128064: return w8 ? launch_mfma2<128, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<128, 64, 2, 2, 4, 1>(d, stream);
-            case 128128: return w8 ? launch_mfma2<128, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<128, 128, 4, 2, 2, 2>(d, stream);
-            default: break;
-            }
-        }
+        const bool w8 = (v2 == 3) || (v2 != 1 && d.cout >= 64);
         switch (key) {
-        //                           CIN  COUT  MB NB WM WN
-        case 32032:  return launch_mfma<32, 32, 2, 1, 4, 1>(d, stream);
-        case 32064:  return launch_mfma<32, 64, 2, 2, 4, 1>(d, stream);
-        case 32128:  return launch_mfma<32, 128, 2, 2, 2, 2>(d, stream);
-        case 64032:  return launch_mfma<64, 32, 2, 1, 4, 1>(d, stream);
-        case 64064:  return launch_mfma<64, 64, 2, 2, 4, 1>(d, stream);
-        case 64128:  return launch_mfma<64, 128, 2, 2, 2, 2>(d, stream);
-        case 128032: return launch_mfma<128, 32, 2, 1, 4, 1>(d, stream);
-        case 128064: return launch_mfma<128, 64, 2, 2, 4, 1>(d, stream);
-        case 128128: return launch_mfma<128, 128, 2, 2, 2, 2>(d, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    if (kind == W2XC_K_MFMA_BF16) {
-        if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
-        switch (d.cin * 1000 + d.cout) {
-        case 32032:  return launch_mfma_bf16<32, 32, 2, 1, 4, 1>(d, stream);
-        case 32064:  return launch_mfma_bf16<32, 64, 2, 2, 4, 1>(d, stream);
-        case 32128:  return launch_mfma_bf16<32, 128, 2, 2, 2, 2>(d, stream);
-        case 64032:  return launch_mfma_bf16<64, 32, 2, 1, 4, 1>(d, stream);
-        case 64064:  return launch_mfma_bf16<64, 64, 2, 2, 4, 1>(d, stream);
-        case 64128:  return launch_mfma_bf16<64, 128, 2, 2, 2, 2>(d, stream);
-        case 128032: return launch_mfma_bf16<128, 32, 2, 1, 4, 1>(d, stream);
-        case 128064: return launch_mfma_bf16<128, 64, 2, 2, 4, 1>(d, stream);
-        case 128128: return launch_mfma_bf16<128, 128, 2, 2, 2, 2>(d, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    if (kind == W2XC_K_FIRST_BF16OUT) {
-        if (d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
-        switch (d.cin * 1000 + d.cout) {
-        case 1032: return launch_tiled8(conv3x3_first<1, 1, bf16_t>, d, stream);
-        case 1064: return launch_tiled8(conv3x3_first<1, 2, bf16_t>, d, stream);
-        case 1128: return launch_tiled8(conv3x3_first<1, 4, bf16_t>, d, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    if (kind == W2XC_K_LAST_BF16IN) {
-        if (d.in_ps != d.cin || d.in_cs != 1) return hipErrorInvalidValue;
-        switch (d.cin * 1000 + d.cout) {
-        case 32001:  return launch_tiled8(conv3x3_last<32, 1, bf16_t>, d, stream);
-        case 64001:  return launch_tiled8(conv3x3_last<64, 1, bf16_t>, d, stream);
-        case 128001: return launch_tiled8(conv3x3_last<128, 1, bf16_t>, d, stream);
+        //                                  CIN  COUT  MB NB WM WN
+        case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);
+        case 32064:  return w8 ? launch_mfma2<32, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<32, 64, 2, 2, 4, 1>(d, stream);
+        case 32128:  return w8 ? launch_mfma2<32, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<32, 128, 4, 2, 2, 2>(d, stream);
+        case 64032:  return launch_mfma2<64, 32, 2, 1, 4, 1>(d, stream);
+        case 64064:  return w8 ? launch_mfma2<64, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<64, 64, 2, 2, 4, 1>(d, stream);
+        case 64128:  return w8 ? launch_mfma2<64, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<64, 128, 4, 2, 2, 2>(d, stream);
+        case 128032: return launch_mfma2<128, 32, 2, 1, 4, 1>(d, stream);
+        case 128064: return w8 ? launch_mfma2<128, 64, 2, 1, 4, 2>(d, stream) : launch_mfma2<128, 64, 2, 2, 4, 1>(d, stream);
+        case 128128: return w8 ? launch_mfma2<128, 128, 2, 2, 4, 2>(d, stream) : launch_mfma2<128, 128, 4, 2, 2, 2>(d, stream);
         default: return hipErrorInvalidValue;
         }
     }
