@@ -1057,6 +1057,27 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
     if constexpr (T == 1) {
+        static const int variant = [] { const char *e = getenv("W2XC_T1_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant == 1) {   // (tuning aid) deeper weight rings: B(t+2) is awaited LOOK = RING - 3 = 5 stages after its issue
+            switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+            case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 8, FMT>(d, stream);
+            case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 4, 8, FMT>(d, stream);
+            case 64128:  return launch_split<64, 128, 4, 2, 2, 2, 1, OT, 2, 8, FMT>(d, stream);
+#endif
+            case 128128: return launch_split<128, 128, 4, 2, 4, 2, 1, OT, 2, 8, FMT>(d, stream);
+            default: break;
+            }
+        }
+        if (variant == 2) {   // (tuning aid) 16-row tiles + ring of 8 for the 64-plane inputs
+            switch (d.cin * 1000 + d.cout) {
+#ifndef W2XC_SPLIT_DEV
+            case 64064:  return launch_split<64, 64, 4, 2, 4, 1, 1, OT, 2, 8, FMT>(d, stream);
+            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, 1, OT, 2, 8, FMT>(d, stream);
+#endif
+            default: break;
+            }
+        }
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
