@@ -56,15 +56,19 @@ inline bool convertWithModels(cv::Mat &inputPlane, cv::Mat &outputPlane,
         if (w2xc_model_from_arrays(n, nin.data(), nout.data(), wp.data(), bp.data(), &m) != W2XC_OK) return false;
         set = std::make_shared<detail::ModelHandle>(m);
     }
-    cv::Mat result(inputPlane.rows, inputPlane.cols, CV_32FC1);   /* staging: in/out may alias */
-    const int rc = w2xc_convert_plane(set->m, reinterpret_cast<const float *>(inputPlane.data), (size_t)inputPlane.step,
-                                      inputPlane.cols, inputPlane.rows, reinterpret_cast<float *>(result.data),
-                                      (size_t)result.step, blockSplitting ? 1 : 0, nullptr);
+    /* the reference (re)allocates the output to the input's size and type (copyTo, :46 / :78).  The engine writes the rows
+     * straight into it -- no staging Mat, no extra 33 MB copy per 4K plane; the C ABI is safe for in == out (in-place). */
+    const int rows = inputPlane.rows, cols = inputPlane.cols;
+    const float *src = reinterpret_cast<const float *>(inputPlane.data);
+    const size_t src_step = (size_t)inputPlane.step;
+    cv::Mat keep = inputPlane;           /* outputPlane may BE inputPlane: create() below must not free the rows being read */
+    outputPlane.create(rows, cols, CV_32FC1);
+    const int rc = w2xc_convert_plane(set->m, src, src_step, cols, rows, reinterpret_cast<float *>(outputPlane.data),
+                                      (size_t)outputPlane.step, blockSplitting ? 1 : 0, nullptr);
     if (rc != W2XC_OK) {
         std::cerr << "w2xc::convertWithModels : " << w2xc_last_error() << std::endl;
         return false;
     }
-    result.copyTo(outputPlane);   /* :46 / :78 */
     return true;
 }
 

@@ -91,6 +91,11 @@ int w2xc_model_from_arrays(int n_layers, const int *nin, const int *nout,
                            const float *const *weight, const double *const *bias, w2xc_model **out);
 
 void w2xc_model_free(w2xc_model *m);
+/* Release what grew with the largest plane converted so far -- activation workspaces, the host pipeline's device rows and
+ * pinned rings, Model::filter's buffers -- on every device the model has run on.  Weights, streams and events stay; the
+ * next call re-grows what it needs.  For a long-lived process after an unusually large image (a 16384^2 plane leaves
+ * 17 GiB of workspace and 1.3 GiB of plane copies behind).  Not to be called concurrently with a conversion on `m`. */
+int  w2xc_model_trim(w2xc_model *m);
 int  w2xc_model_layers(const w2xc_model *m);             /* models.size()                          */
 int  w2xc_model_nin(const w2xc_model *m, int layer);     /* Model::getNInputPlanes  (:18-20)        */
 int  w2xc_model_nout(const w2xc_model *m, int layer);    /* Model::getNOutputPlanes (:22-24)        */

@@ -110,6 +110,32 @@ def test_host_pipeline_pinned_and_strided_planes(gpu, noise1_layers):
     assert np.array_equal(ro, want) and pg_out[1].max() == -7.0 and pg_out[:, :4].max() == -7.0
 
 
+def test_in_place_conversion_and_trim(gpu, scale_layers):
+    """in == out (the reference never does it, main.cpp:94-96 copies first; a library must survive it): with several workspace
+    bands the drainer writes band b's rows while band b+1's source rows have yet to be read -- unless every source row is staged
+    first, which is what overlapping planes get.  Then w2xc_model_trim: buffers released, the next call re-grows them."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = rand_plane(400, 300, 41)
+    want = ms.convert(x)
+    lib = gpu.lib()
+    for band in (0, 64):
+        buf = x.copy()
+        o = gpu.make_opts(band_rows=band)
+        import ctypes as C
+        assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, buf.strides[0], 300, 400, buf.ctypes.data, buf.strides[0], 1, C.byref(o)) == 0
+        assert np.array_equal(buf, want), "band_rows=%d" % band
+    # partially overlapping: output plane shifted by 5 rows inside the same allocation
+    big = np.zeros((405, 300), np.float32)
+    big[5:] = x
+    o = gpu.make_opts(band_rows=64)
+    assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, C.byref(o)) == 0
+    assert np.array_equal(big[:400], want)
+    ms.trim()
+    assert np.array_equal(ms.convert(x), want)
+    ms.trim()
+    assert np.array_equal(ms.filter(0, x[None])[3], ms.filter(0, x[None], opts=gpu.make_opts(kernel=gpu.KERNEL_AUTO))[3])
+
+
 @pytest.mark.parametrize("nn2x", [0, 1])
 @pytest.mark.parametrize("parts", [2, 5])
 def test_farm_units_from_host_memory(gpu, scale_layers, parts, nn2x):

@@ -64,6 +64,7 @@ def _load():
         "w2xc_model_load_json": (ci, [C.c_char_p, C.POINTER(vp)]),
         "w2xc_model_from_arrays": (ci, [ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "w2xc_model_free": (None, [vp]),
+        "w2xc_model_trim": (ci, [vp]),
         "w2xc_model_layers": (ci, [vp]),
         "w2xc_model_nin": (ci, [vp, ci]),
         "w2xc_model_nout": (ci, [vp, ci]),
@@ -209,6 +210,12 @@ class _ModelSet:
         if rc != OK:
             raise W2xcError(rc, last_error())
         return cls(h.value)
+
+    def trim(self):
+        """release the buffers that grew with the largest plane so far (w2xc_model_trim); weights stay resident"""
+        rc = _lib.w2xc_model_trim(self.handle)
+        if rc != OK:
+            raise W2xcError(rc, last_error())
 
     @property
     def n_layers(self):

@@ -778,6 +778,35 @@ int w2xc_model_load_json(const char *path, w2xc_model **out)
 }
 
 void w2xc_model_free(w2xc_model *m) { delete m; }
+
+int w2xc_model_trim(w2xc_model *m)
+{
+    if (!m) return fail(W2XC_ERR_ARG, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    int prev = 0;
+    hipGetDevice(&prev);
+    for (auto &kv : m->ctx) {
+        DevCtx *c = kv.second.get();
+        std::lock_guard<std::mutex> lk2(c->mu);
+        hipSetDevice(c->device);
+        hipDeviceSynchronize();
+        for (int i = 0; i < 2; i++) {
+            if (c->ws[i]) { hipFree(c->ws[i]); c->ws[i] = nullptr; c->ws_floats[i] = 0; }
+            if (c->fc.planar[i]) { hipFree(c->fc.planar[i]); c->fc.planar[i] = nullptr; c->fc.planar_floats[i] = 0; }
+            if (c->fc.nhwc[i]) { hipFree(c->fc.nhwc[i]); c->fc.nhwc[i] = nullptr; c->fc.nhwc_floats[i] = 0; }
+        }
+        c->fc.res_valid = false;
+        if (c->aux) { hipFree(c->aux); c->aux = nullptr; c->aux_floats = 0; }
+        if (c->img_io) { hipFree(c->img_io); c->img_io = nullptr; c->img_io_bytes = 0; }
+        HostPipe &p = c->pipe;
+        if (p.d_in) { hipFree(p.d_in); p.d_in = nullptr; p.d_in_bytes = 0; }
+        if (p.d_out) { hipFree(p.d_out); p.d_out = nullptr; p.d_out_bytes = 0; }
+        if (p.pin_in) { hipHostFree(p.pin_in); p.pin_in = nullptr; p.in_slot_bytes = 0; }
+        if (p.pin_out) { hipHostFree(p.pin_out); p.pin_out = nullptr; p.out_slot_bytes = 0; }
+    }
+    hipSetDevice(prev);
+    return W2XC_OK;
+}
 int w2xc_model_layers(const w2xc_model *m) { return m ? (int)m->layers.size() : 0; }
 int w2xc_model_nin(const w2xc_model *m, int l) { return (m && l >= 0 && l < (int)m->layers.size()) ? m->layers[l].nin : -1; }
 int w2xc_model_nout(const w2xc_model *m, int l) { return (m && l >= 0 && l < (int)m->layers.size()) ? m->layers[l].nout : -1; }
@@ -1014,8 +1043,13 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         }
         return W2XC_OK;
     };
+    // in-place / overlapping planes (the reference never does this, main.cpp:94-96 copies first; a library must survive it):
+    // the drainer writes band b's rows while later bands still read theirs, so every source row is staged before any output exists
+    const char *in_lo = (const char *)in + (size_t)sy0 * in_stride, *in_hi = (const char *)in + (size_t)(sy1 - 1) * in_stride + in_row;
+    const char *out_lo = (const char *)out + (size_t)ra * out_stride, *out_hi = (const char *)out + (size_t)(rb - 1) * out_stride + out_row;
+    const bool overlap = in_lo < out_hi && out_lo < in_hi;
     // view rows (source coordinates, relative to sy0) a band of output rows [y0, y1) reads
-    auto band_src_end = [&](int y1) { return ((std::min(H, y1 + n) + up) >> up) - sy0; };
+    auto band_src_end = [&](int y1) { return overlap ? svh : ((std::min(H, y1 + n) + up) >> up) - sy0; };
 
     // ---- output side ----
     struct Chunk { int r0, r1, slot; };
