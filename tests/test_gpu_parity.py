@@ -174,7 +174,7 @@ def test_golden_fixtures_on_gpu(gpu):
         if not f.endswith(".npz"):
             continue
         g = np.load(os.path.join(GOLDEN, f))
-        layers = gen_model.synth_layers([int(v) for v in g["planes"]], int(g["seed"]))
+        layers = gen_model.synth_layers([int(v) for v in g["planes"]], int(g["seed"]), init=str(g["init"]) if "init" in g else "he_leaky")
         ms = gpu._ModelSet.from_layers(layers)
         assert_close(ms.convert(g["input"]), g["output"], f)
         assert np.array_equal(ms.convert(g["input"], opts=direct(gpu)), g["output"]), f

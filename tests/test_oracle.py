@@ -131,7 +131,7 @@ def test_golden_fixtures(oracle_built):
     for f in files:
         g = np.load(os.path.join(GOLDEN, f))
         planes = [int(v) for v in g["planes"]]
-        layers = gen_model.synth_layers(planes, int(g["seed"]))
+        layers = gen_model.synth_layers(planes, int(g["seed"]), init=str(g["init"]) if "init" in g else "he_leaky")
         o = orc.Oracle(layers)
         got = o.convert(g["input"], block=(int(g["block"]), int(g["block"])))
         assert np.array_equal(got, g["output"]), f

@@ -446,6 +446,10 @@ struct BandHooks {
     int out_chunk_rows = 0;                              // > 0: the last layer of a band is launched in row chunks of at most this size,
     int out_chunk_min = 0;                               //      tapering to this size at the end of the band (the exposed D2H tail)
     std::function<int(int, int)> input_needed;           // before layer 1 of band [y0, y1): make the launch stream wait for its input rows
+    // layer 1 in row chunks while the band's input is still arriving: in_chunk(y0, y1) > 0 = output rows of layer 1 per chunk
+    // (0: the band's rows are already staged / one launch); input_upto(v) = make the launch stream wait for view rows <= v
+    std::function<int(int, int)> in_chunk;
+    std::function<int(int)> input_upto;
     std::function<int(int, int)> prefetch;               // layers 1..n-1 of the current band are enqueued; [y0, y1) = the NEXT band
     std::function<int(int, int)> output_ready;           // output rows [r0, r1) have been enqueued on the launch stream
 };
@@ -539,7 +543,10 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
 
     for (int y0 = ra; y0 < rb; y0 += band) {
         const int y1 = std::min(rb, y0 + band);
-        if (hk && hk->input_needed) { int rc = hk->input_needed(y0, y1); if (rc) return rc; }
+        // layer 1 of this band in row chunks (each waits only for the rows it reads) or in one launch behind the whole upload
+        const W2xcKernelKind kind1 = layer_kind(m, 0, o);
+        const int in_chunk = (hk && hk->in_chunk && hk->input_upto && n > 1 && (kind1 == W2XC_K_FIRST || kind1 == W2XC_K_DIRECT)) ? hk->in_chunk(y0, y1) : 0;
+        if (hk && hk->input_needed && in_chunk <= 0) { int rc = hk->input_needed(y0, y1); if (rc) return rc; }
         const float *src = d_in;
         long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs, src_ts = 0, src_gs = 0;
         int src_halves = 0;
@@ -598,6 +605,24 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (hk && k == n && hk->prefetch && y1 < rb) {   // stage the next band's input while this one computes
                 int rc = hk->prefetch(y1, std::min(rb, y1 + band));
                 if (rc) return rc;
+            }
+            if (k == 1 && in_chunk > 0) {
+                // the upload of rows [c0 + 2 + off_y ...] and layer 1 of the rows before them overlap: what stays exposed of the
+                // input side is the first slice and the last chunk, not upload + layer 1 back to back
+                for (int c0 = 0; c0 < d.out_h; c0 += in_chunk) {
+                    W2xcConvDesc dd = d;
+                    dd.out_h = std::min(in_chunk, d.out_h - c0);
+                    dd.out = d.out + (size_t)c0 * d.out_rs;
+                    dd.off_y = d.off_y + c0;
+                    const int vlast = std::min(std::max(c0 + dd.out_h - 1 + 2 + d.off_y, 0), d.in_h - 1);   // last view row this chunk reads
+                    int rc = hk->input_upto(vlast);
+                    if (rc) return rc;
+                    rc = launch_layer(c, m, 0, kind, dd, st, o.profile != 0);
+                    if (rc) return rc;
+                }
+                src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs; src_halves = d.halves;
+                src_h = d.out_h; src_w = d.out_w;
+                continue;
             }
             const bool chunked = hk && k == n && direct_out && hk->out_chunk_rows > 0 && d.out_h > std::max(hk->out_chunk_min, 8) &&
                                  (kind == W2XC_K_LAST || kind == W2XC_K_LAST_GATHER || kind == W2XC_K_DIRECT);
@@ -1110,6 +1135,18 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         return W2XC_OK;
     };
     hk.prefetch = [&](int, int y1n) -> int { return upload_to(band_src_end(y1n)); };
+    // a band whose rows were prefetched under the previous band is launched whole; otherwise layer 1 follows the upload slice by slice
+    hk.in_chunk = [&](int, int y1) -> int {
+        if (overlap || uploaded >= std::min(band_src_end(y1), svh)) return 0;
+        return std::max(8, ((in_chunk_rows << up) + 7) & ~7);
+    };
+    hk.input_upto = [&](int vlast) -> int {
+        int r = upload_to((vlast >> up) + 1);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(p.ev_input, p.s_h2d));
+        HIP_TRY(hipStreamWaitEvent(p.s_compute, p.ev_input, 0));
+        return W2XC_OK;
+    };
     hk.output_ready = [&](int r0, int r1) -> int {
         HIP_TRY(hipEventRecord(p.ev_chunk, p.s_compute));
         HIP_TRY(hipStreamWaitEvent(p.s_d2h, p.ev_chunk, 0));
