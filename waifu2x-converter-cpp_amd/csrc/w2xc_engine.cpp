@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
@@ -1179,9 +1180,17 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         return W2XC_OK;
     };
 
+    static const bool trace = getenv("W2XC_HOST_TRACE") != nullptr;   // (debug aid) phase timestamps of one unit on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk);
+    const double t_enq = ms_since(t0);
+    double t_comp = 0;
+    if (trace) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
     std::string err = g_last_error;
     finish_drainer();
+    if (trace) fprintf(stderr, "[w2xc host] rows %d..%d: enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s)\n", ra, rb, t_enq, t_comp,
+                       ms_since(t0), in_pinned ? "pinned" : "pageable", out_pinned ? "pinned" : "pageable");
     // leave nothing in flight, whatever happened: the pipe and the caller's planes are reused by the next call
     hipError_t e1 = hipStreamSynchronize(p.s_h2d), e2 = hipStreamSynchronize(p.s_compute), e3 = hipStreamSynchronize(p.s_d2h);
     if (rc) { g_last_error = err; return rc; }
