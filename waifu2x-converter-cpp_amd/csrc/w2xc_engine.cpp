@@ -1124,6 +1124,10 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
             drainer.join();
         }
     };
+    struct AtExit {   // an exception below (std::bad_alloc in a queue) must not unwind past a joinable thread
+        std::function<void()> f;
+        ~AtExit() { f(); }
+    } join_guard{finish_drainer};
 
     BandHooks hk;
     hk.out_chunk_rows = out_chunk_rows;
