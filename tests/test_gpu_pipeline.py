@@ -71,6 +71,9 @@ def test_host_pipeline_multi_band_and_every_last_layer_kernel(gpu, scale_layers,
          {"precision": {"fp32": gpu.PRECISION_FP32, "fp16x2": gpu.PRECISION_FP16X2, "bf16": gpu.PRECISION_BF16}[precision]}
     x = rand_plane(333, 260, 8)
     one = device_result(gpu, ms, x, **kw)
+    # one band through the host pipeline: chunked last layer (fp32 / direct) or layer 6 + gather chunked together (16-bit modes)
+    assert np.array_equal(ms.convert(x, opts=gpu.make_opts(**kw)), one)
+    assert np.array_equal(ms.convert_nn2x(x[:170, :131], opts=gpu.make_opts(**kw)), device_result(gpu, ms, x[:170, :131], True, **kw))
     banded = ms.convert(x, opts=gpu.make_opts(band_rows=100, **kw))
     assert np.array_equal(banded, device_result(gpu, ms, x, band_rows=100, **kw))
     if precision in ("fp32", "direct"):

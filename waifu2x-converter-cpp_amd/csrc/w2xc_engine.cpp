@@ -603,6 +603,43 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     d.halves = w2xc_split_halves(T, hl.nout);
                 }
             }
+            // 16-bit modes, host pipeline: the last layer lives in layer n-1's epilogue + a 0.2 ms gather, too short to hide the
+            // band's download behind.  So layer n-1 and the gather run TOGETHER in row chunks (quarters of the band, whole 16-row
+            // tiles): chunk j's rows leave for the host under layer n-1 of chunk j+1.  The producer chunks tile the G rows without
+            // overlap (chunk j computes G rows up to r1 + 2, the next one continues there): no recompute.
+            if (hk && T > 0 && k == n - 1 && n >= 3 && kind == W2XC_K_MID_SPLIT && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
+                hk->output_ready && (y1 - y0) >= 128) {
+                if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
+                const int R = y1 - y0;
+                const int cr = std::max(64, ((R / 4) + 15) & ~15);
+                int g_done = 0;
+                for (int r0 = 0; r0 < R;) {
+                    int r1 = std::min(R, r0 + cr);
+                    if (R - r1 < 32) r1 = R;
+                    const int g1 = r1 + 2;                       // the gather of rows [r0, r1) reads G rows [r0, r1 + 2)
+                    W2xcConvDesc dd = d;
+                    dd.out_h = g1 - g_done;
+                    dd.off_y = d.off_y + g_done;
+                    dd.out = d.out + (size_t)g_done * d.out_rs;  // (plane / half strides stay those of the whole band)
+                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o.profile != 0);
+                    if (rc) return rc;
+                    g_done = g1;
+                    W2xcConvDesc dg;
+                    memset(&dg, 0, sizeof dg);
+                    dg.in = d.out + (size_t)r0 * d.out_rs; dg.in_rs = d.out_rs; dg.in_ps = d.out_ps; dg.in_cs = d.out_cs;
+                    dg.in_ts = d.out_ts; dg.in_gs = d.out_gs; dg.halves = d.halves; dg.fmt = d.fmt;
+                    dg.in_h = r1 - r0 + 2; dg.in_w = d.out_w;
+                    dg.out_h = r1 - r0; dg.out_w = w;
+                    dg.out = d_out + (size_t)(y0 - ra + r0) * out_stride_f;
+                    dg.out_rs = (long long)out_stride_f; dg.out_ps = 1; dg.out_cs = out_cs;
+                    rc = launch_layer(c, m, n - 1, W2XC_K_LAST_GATHER, dg, st, o.profile != 0);
+                    if (rc) return rc;
+                    rc = hk->output_ready(y0 + r0, y0 + r1);
+                    if (rc) return rc;
+                    r0 = r1;
+                }
+                break;
+            }
             if (hk && k == n && hk->prefetch && y1 < rb) {   // stage the next band's input while this one computes
                 int rc = hk->prefetch(y1, std::min(rb, y1 + band));
                 if (rc) return rc;
