@@ -5,6 +5,7 @@
 //   dropin_hip : -Iinclude/w2xc      + libw2xc_hip.so                                   (same shim for cv::Mat)
 // usage: dropin_xxx convert model.json in.f32 w h out.f32 [block_splitting]
 //        dropin_xxx filter  model.json layer in.f32 nplanes w h out.f32
+//        dropin_xxx chain   model.json in.f32 w h out.f32          (every layer through Model::filter, test.cpp:72-85)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,25 @@ int main(int argc, char **argv)
                 for (int y = 0; y < h; y++)
                     for (int x = 0; x < w; x++) out[(o * h + y) * w + x] = op[o].at<float>(y, x);
             if (!write_all(argv[8], out.data(), out.size())) rc = 5;
+        }
+    } else if (!strcmp(argv[1], "chain") && argc >= 7) {
+        // the reference's test.cpp:72-85 pattern: filter() layer after layer, each call's output vector handed to the next
+        if (!w2xc::modelUtility::generateModelFromJSON(argv[2], models)) return 3;
+        const int w = atoi(argv[4]), h = atoi(argv[5]);
+        std::vector<float> in((size_t)w * h);
+        if (!read_all(argv[3], in)) return 4;
+        std::vector<cv::Mat> cur, nxt;
+        cur.push_back(cv::Mat(h, w, CV_32FC1, in.data()));
+        for (size_t l = 0; l < models.size() && rc == 0; l++) {
+            if (!models[l]->filter(cur, nxt)) rc = 1;
+            else cur = nxt;
+        }
+        if (rc == 0) {
+            std::vector<float> out(cur.size() * (size_t)w * h);
+            for (size_t o = 0; o < cur.size(); o++)
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) out[(o * h + y) * w + x] = cur[o].at<float>(y, x);
+            if (!write_all(argv[6], out.data(), out.size())) rc = 5;
         }
     } else {
         rc = 2;

@@ -97,3 +97,22 @@ def test_same_caller_filter(bins, models_dir, tmp_path):
     assert_close(outs[1], outs[0], "dropin filter")
     r = subprocess.run([bins[1], "filter", model, "1", fin, "5", "33", "20", str(tmp_path / "x.f32")], capture_output=True, text=True)
     assert r.returncode == 1 and "number of input planes mismatch" in r.stderr
+
+
+@pytest.mark.gpu
+def test_same_caller_filter_chain_resident_or_not(bins, models_dir, tmp_path):
+    """test.cpp:72-85: all 7 layers through Model::filter by hand, the SAME binary with and without W2XC_FILTER_RESIDENT=1 (planes
+    handed straight back are taken from the copy still on the GPU) -- bit-identical to each other, inside the tolerance vs the
+    reference build of the same caller"""
+    model = os.path.join(models_dir, "noise1_model.json")
+    x = rand_plane(37, 52, 6)
+    fin = str(tmp_path / "c.f32")
+    x.tofile(fin)
+    outs = {}
+    for tag, b, env in (("ref", bins[0], {}), ("hip", bins[1], {}), ("hip_resident", bins[1], {"W2XC_FILTER_RESIDENT": "1"})):
+        fout = str(tmp_path / (tag + ".f32"))
+        r = subprocess.run([b, "chain", model, fin, "52", "37", fout], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs[tag] = np.fromfile(fout, np.float32).reshape(1, 37, 52)
+    assert np.array_equal(outs["hip"], outs["hip_resident"])
+    assert_close(outs["hip"], outs["ref"], "dropin filter chain")
