@@ -105,18 +105,8 @@ __global__ void __launch_bounds__(256) conv3x3_direct(W2xcConvDesc d, int cout_p
 // ------------------------------------------------------------------------------------------------
 
 template <int CIN, int COUT, int MB, int NB, int WM, int WN, int EPI = 1>
-__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles, int bh)
+__global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcConvDesc d, int tiles_x, int ntiles)
 {
-    // tile list order: bh <= 1 row-major; else bands of bh tile rows walked column by column, so the 32 workgroups of an XCD
-    // (32 consecutive list entries) cover a bh-rows x (32 / bh)-columns block and share their halo rows in that XCD's L2
-    const int tiles_y = ntiles / tiles_x;
-    auto tile_xy = [&](int t, int &ty, int &tx) {
-        if (bh <= 1) { ty = t / tiles_x; tx = t - ty * tiles_x; return; }
-        const int per_band = bh * tiles_x, band = t / per_band, r = t - band * per_band;
-        const int rows_here = (tiles_y - band * bh) < bh ? (tiles_y - band * bh) : bh;
-        tx = r / rows_here;
-        ty = band * bh + (r - tx * rows_here);
-    };
     constexpr int NST = MB * NB * 16;                // stores per wave in an interior-tile epilogue
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
     constexpr int NSL = CIN / 32, NBT = COUT / 32;
@@ -164,8 +154,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
         lofs[jj] = (unsigned)(((long long)py * d.in_rs + (long long)px * CIN) >> 2) + ((s & 7) ^ ((p >> 1) & 7));
     }
     auto tile_offsets = [&](int t) {
-        int ty_, tx_;
-        tile_xy(t, ty_, tx_);
+        const int ty_ = t / tiles_x, tx_ = t - ty_ * tiles_x;
         const int y0 = ty_ * ROWS + d.off_y, x0 = tx_ * 32 + d.off_x;
         if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
             const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * CIN) >> 2);
@@ -339,8 +328,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
             // ---- epilogue: bias + LeakyReLU, NHWC stores (C/D: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)).
             //      leaky(v) = max(v, 0.1f*v).  Interior tiles (all but the last row / column of tiles)
             //      take the unpredicated path. ----
-            int tile_y, tile_x;
-            tile_xy(tile, tile_y, tile_x);
+            const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
             const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
             const bool interior = (oy0 + ROWS <= d.out_h) && (ox0 + 32 <= d.out_w);
             float *obase = d.out + (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + 4 * kk) * COUT + nb0 * 32 + li;
@@ -662,8 +650,7 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((ntiles + 7) & ~7)) grid = (ntiles + 7) & ~7;
-    static const int bh = [] { const char *e = getenv("W2XC_MFMA_BH"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles, bh);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, tiles_x, ntiles);
     return hipGetLastError();
 }
 
