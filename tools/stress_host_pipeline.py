@@ -12,6 +12,8 @@ from tools import gen_model
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--max-h", type=int, default=700)
+ap.add_argument("--max-w", type=int, default=900)
 a = ap.parse_args()
 w2xc = graft.load_package()
 ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(seed=102))
@@ -19,7 +21,7 @@ rng = np.random.default_rng(12345)
 st = torch.cuda.current_stream()
 bad = 0
 for it in range(a.iters):
-    h, w = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+    h, w = int(rng.integers(1, a.max_h)), int(rng.integers(1, a.max_w))
     nn2x = bool(rng.integers(0, 2))
     prec = [w2xc.PRECISION_FP32, w2xc.PRECISION_FP32, w2xc.PRECISION_FP16X2, w2xc.PRECISION_BF16][int(rng.integers(0, 4))]
     band = [0, 0, 37, 128, 200][int(rng.integers(0, 5))]
