@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     constexpr int NST = OT == 9 ? MB * 5 : MB * NB * 4 * (OT ? OT : 1);  // store instructions of an interior-tile epilogue
     static_assert((NW == 4 || NW == 8) && (ROWS == 8 || ROWS == 16) && NB * WN == NBT, "tile shape");
     static_assert(CIN % (16 * KG) == 0 && COUT % 32 == 0 && A_SLOTS % 64 == 0, "planes");
-    static_assert((E == 1 || E == 3) && RING >= 2 * E + 2 && RING <= 8 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
+    static_assert((E == 1 || E == 3) && RING >= 2 * E + 2 && RING <= 12 && LEAD <= 9 && (APW + LASTA) / (LASTA + 1) <= 4, "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
@@ -1057,6 +1057,13 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
     if constexpr (T == 1) {
+        static const int variant = [] { const char *e = getenv("W2XC_T1_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant >= 1 && variant <= 3 && (d.cout == 128 && d.cin >= 64)) {   // (tuning aid) 8-row tiles, rings of 10-12
+            const bool c64 = d.cin == 64;
+            if (variant == 1) return c64 ? launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream) : launch_split<128, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream);
+            if (variant == 2) return c64 ? launch_split<64, 128, 4, 2, 2, 2, 1, OT, 2, 11, FMT, 3>(d, stream) : launch_split<128, 128, 4, 2, 2, 2, 1, OT, 2, 11, FMT, 3>(d, stream);
+            if (variant == 3) return c64 ? launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 10, FMT, 1>(d, stream) : launch_split<128, 128, 2, 2, 4, 2, 1, OT, 2, 10, FMT, 1>(d, stream);
+        }
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
