@@ -1057,13 +1057,6 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
     if constexpr (T == 1) {
-        static const int variant = [] { const char *e = getenv("W2XC_T1_VARIANT"); return e ? atoi(e) : 0; }();
-        if (variant >= 1 && variant <= 3 && (d.cout == 128 && d.cin >= 64)) {   // (tuning aid) 8-row tiles, rings of 10-12
-            const bool c64 = d.cin == 64;
-            if (variant == 1) return c64 ? launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream) : launch_split<128, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream);
-            if (variant == 2) return c64 ? launch_split<64, 128, 4, 2, 2, 2, 1, OT, 2, 11, FMT, 3>(d, stream) : launch_split<128, 128, 4, 2, 2, 2, 1, OT, 2, 11, FMT, 3>(d, stream);
-            if (variant == 3) return c64 ? launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 10, FMT, 1>(d, stream) : launch_split<128, 128, 2, 2, 4, 2, 1, OT, 2, 10, FMT, 1>(d, stream);
-        }
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
@@ -1074,8 +1067,10 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         //   64->64    8 rows, 4 waves, 64-channel stages, ring of 8 instead of 4: 0.74 -> 0.67 ms.  A stage of these kernels lasts
         //             0.5-1k cycles, so with a ring of 4 a weight stage is awaited ONE stage (< 0.5 us) after its issue -- less than
         //             an L2 round trip under load; 8 slots put 5 stages between issue and use.  (32->64 also runs a ring of 8.)
-        //   64->128 and the rest: 8 rows, 4 waves, 64-channel stages, ring of 4 (16 KiB stages: no room for more; the 32-channel
-        //             / 16-row forms that have room measured 4-15 % slower; 4x4 blocks for 128 planes spill ~290 registers)
+        //   64->128   8 rows, 8 waves (2x2 blocks), 32-channel stages, ring of 12 with one barrier per 3 taps (LOOK = 5 stages between
+        //             a weight stage's issue and its use): 1.28 -> 1.16 ms.  (Its 64-channel stages are 16 KiB -- a ring of 4 is all
+        //             that fits; the 16-row forms measured 4-15 % slower; 4x4 blocks for 128 planes spill ~290 registers.)
+        //   the rest: 8 rows, 4 waves, 64-channel stages, ring of 4
         switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV
         case 32032:  return launch_split<32, 32, 2, 1, 4, 1, 1, OT, 2, 4, FMT>(d, stream);
@@ -1083,7 +1078,7 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         case 32128:  return launch_split<32, 128, 4, 2, 2, 2, 1, OT, 2, 4, FMT>(d, stream);
         case 64032:  return launch_split<64, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 4, 8, FMT>(d, stream);
-        case 64128:  return launch_split<64, 128, 4, 2, 2, 2, 1, OT, 4, 4, FMT>(d, stream);
+        case 64128:  return launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream);
         case 128032: return launch_split<128, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 128064: return launch_split<128, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
 #endif
