@@ -1056,10 +1056,7 @@ template <int T, int OT, int FMT>
 static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
 {
     constexpr bool BIG = (T == 2);
-    static const int variant = [] { const char *e = getenv("W2XC_SPLIT_VARIANT"); return e ? atoi(e) : 0; }();   // (tuning aid)
     if constexpr (T == 1) {
-        if (variant == 1 && d.cin == 64 && d.cout == 64) return launch_split<64, 64, 4, 2, 4, 1, 1, OT, 2, 10, FMT, 3>(d, stream);
-        if (variant == 2 && d.cin == 64 && d.cout == 64) return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 2, 11, FMT, 3>(d, stream);
         // One term (32-cycle MFMAs, one product per operand pair): the fragment reads of an 8-row tile with 2x2 blocks draw
         // the LDS's whole 128 bytes per clock, so the tilings below were picked by measurement (round 2, same box, same run):
         //   32->64    16 rows, 4 waves owning all 64 planes of 4 rows each (4x2 blocks), 32-channel stages, ring of 6:
@@ -1090,18 +1087,6 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         }
     }
     constexpr int KG = 1, RG = 6;
-    if constexpr (BIG && OT != 9) {
-        if (variant == 3) {   // two terms: ring of 8 (5 stages between issue and use)
-            switch (d.cin * 1000 + d.cout) {
-#ifndef W2XC_SPLIT_DEV
-            case 32064:  return launch_split<32, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT>(d, stream);
-            case 64064:  return launch_split<64, 64, 4, 1, 4, 2, T, OT, KG, 8, FMT>(d, stream);
-            case 64128:  return launch_split<64, 128, 4, 2, 4, 2, T, OT, KG, 8, FMT>(d, stream);
-#endif
-            default: break;
-            }
-        }
-    }
     switch (d.cin * 1000 + d.cout) {
 #ifndef W2XC_SPLIT_DEV   // (development aid: -DW2XC_SPLIT_DEV instantiates 128->128 only)
     //                                     CIN  COUT  MB NB WM WN
