@@ -189,6 +189,40 @@ def test_argument_validation(w2xc, noise1_layers):
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
 
 
+def test_farm_unit_argument_contract(w2xc, noise1_layers):
+    """w2xc_convert_plane_rows validates the unit BEFORE it looks for a device: the source view must cover exactly the rows the
+    row range reads -- [row_begin - n, row_end + n) of the plane, halved (rounded outwards) when the nearest-2x is fused -- so the
+    row arithmetic of the multi-GPU farm is checkable without a GPU (a valid unit then fails with ERR_HIP here, never on the CPU)."""
+    ms = w2xc._ModelSet.from_layers(noise1_layers)
+    lib = w2xc.lib()
+    n, h, w = ms.n_layers, 100, 64
+    src = np.zeros((h, w), np.float32)
+    ok_code = w2xc.OK if w2xc.device_count() > 0 else w2xc.ERR_HIP
+
+    def call(view_y0, view_h, nn2x, rb, re):
+        out = np.zeros((max(re - rb, 1), w << nn2x), np.float32)
+        v = src[view_y0:view_y0 + view_h]
+        return lib.w2xc_convert_plane_rows(ms.handle, v.ctypes.data, v.strides[0], view_y0, view_h, w, h, nn2x, rb, re,
+                                           out.ctypes.data, out.strides[0], None)
+    for nn2x in (0, 1):
+        H = h << nn2x
+        for parts in (1, 2, 3, 7):
+            for p in range(parts):
+                rb, re = w2xc.shard_rows(H, parts, p)
+                y0, y1 = w2xc.shard_view(H, rb, re, n)                      # plane rows the unit reads (output coordinates)
+                sy0, sy1 = y0 >> nn2x, (y1 + nn2x) >> nn2x                   # ... as source rows
+                assert call(sy0, sy1 - sy0, nn2x, rb, re) == ok_code, (nn2x, parts, p)
+                if sy0 > 0:
+                    assert call(sy0 + 1, sy1 - sy0 - 1, nn2x, rb, re) == w2xc.ERR_ARG      # first halo row missing
+                if sy1 < h:
+                    assert call(sy0, sy1 - sy0 - 1, nn2x, rb, re) == w2xc.ERR_ARG          # last halo row missing
+        assert call(0, h, nn2x, 10, 10) == w2xc.ERR_ARG                       # empty range
+        assert call(0, h, nn2x, -1, 5) == w2xc.ERR_ARG
+        assert call(0, h, nn2x, 0, H + 1) == w2xc.ERR_ARG
+        assert call(0, h + 1, nn2x, 0, H) == w2xc.ERR_ARG                     # view longer than the plane
+    assert call(0, h, 2, 0, h) == w2xc.ERR_ARG                                # nn2x is 0 or 1
+
+
 def test_no_cpu_fallback_without_gpu(w2xc, noise1_layers):
     """On a box without a HIP device the product path must fail, never compute on the CPU."""
     if w2xc.device_count() > 0:
