@@ -1,6 +1,7 @@
 """Emulation of the W2XC_PRECISION_BF16 path for tests (TEST INFRASTRUCTURE): same dataflow as the HIP
 engine -- fp32 first layer, activations rounded to bf16 (RNE) between layers, bf16 weights on the middle
-layers, fp32 last layer -- with float64 accumulation (the GPU accumulates in fp32 in MFMA order, so
+layers and on a one-plane last layer that is computed inside the epilogue of the layer before it (fused:
+3 or more layers, mid-layer plane counts), fp32 weights on any other last layer -- with float64 accumulation (the GPU accumulates in fp32 in MFMA order, so
 individual bf16 roundings may differ by one ulp; tolerances in the tests account for that)."""
 import numpy as np
 import torch
@@ -17,7 +18,9 @@ def convert_bf16_emulated(layers, plane):
     t = F.pad(t, (n, n, n, n), mode="replicate")
     for k, (nin, nout, w, b) in enumerate(layers):
         wt = torch.from_numpy(w).to(torch.float64)
-        if 0 < k < n - 1:
+        mid = lambda c: c in (32, 64, 128)
+        fused_last = (n >= 3 and k == n - 1 and nout == 1 and mid(nin) and mid(layers[n - 2][0]))
+        if 0 < k < n - 1 or fused_last:
             wt = _bf16(wt)
         t = F.conv2d(t, wt, torch.from_numpy(b.astype(np.float32)).to(torch.float64))
         t = torch.where(t > 0, t, np.float64(np.float32(0.1)) * t)

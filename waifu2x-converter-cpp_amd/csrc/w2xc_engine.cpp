@@ -80,8 +80,8 @@ struct DevLayer {
     float *w_direct = nullptr;
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
-    float *w_last_fused[3] = {nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms
-    float last_fused_scale[3] = {1, 1, 1};
+    float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
+    float last_fused_scale[4] = {1, 1, 1, 1};
     float *bias = nullptr;
 };
 
@@ -411,7 +411,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         if (d.out_terms == 9) {   // the next (last) layer's weights ride along
             DevLayer &nl = c->layers[l + 1];
             const int nin = m->layers[l + 1].nin;
-            const int lt = d.terms == 3 ? 3 : 2, li = d.terms == 3 ? 2 : d.fmt;
+            const int lt = d.terms, li = d.terms == 3 ? 2 : d.terms == 1 ? 3 : d.fmt;   // the fused product uses the mode's own term count
             if (!nl.w_last_fused[li]) {
                 std::vector<float> pk((w2xc_split_pack_last_bytes(nin, lt) + 3) / 4);
                 nl.last_fused_scale[li] = w2xc_split_pack_last(nin, lt, d.fmt, m->layers[l + 1].w.data(), pk.data());

@@ -64,9 +64,47 @@ static __device__ __forceinline__ unsigned pk_f16(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_t));
 }
 
+// LeakyReLU(0.1) of an MFMA accumulator register: median(s, 0.1 s, FLT_MAX) = max(s, 0.1 s) for every finite s.
+// (fmaxf on a raw accumulator costs a second v_max_f32 -- the IEEE-mode canonicalisation of an operand the compiler cannot
+// prove quiet; v_med3_f32 has no such requirement.)
+static __device__ __forceinline__ float leaky_acc(float s) { return __builtin_amdgcn_fmed3f(s, 0.1f * s, 3.402823466e+38f); }   // (FLT_MAX: with +inf the compiler folds it back to fmaxf)
+
 // Store 4 consecutive channels of one pixel as OT term planes (OT >= 1) or as fp32 (OT == 0).
 // FMT = 0: bf16 terms (same exponent range as fp32).  FMT = 1: fp16 terms -- values are clamped to the fp16
 // range (+-65504) first; residuals below 2^-14 are held to 2^-25 absolute by fp16's subnormals.
+typedef __attribute__((address_space(1))) char gbyte_t;   // a byte of global memory
+// `base` = byte address of the quad's first element in term plane 0 (fp32 NHWC when OT == 0), `ts_bytes` = bytes between term planes.
+template <int OT, int FMT>
+static __device__ __forceinline__ void store_terms_at(gbyte_t *base, long long ts_bytes, float v0, float v1, float v2, float v3)
+{
+    if (OT == 0 || OT == 9) {   // (OT == 9, the fused-last-layer epilogue, never gets here)
+        *(__attribute__((address_space(1))) f32x4 *)(base) = (f32x4){v0, v1, v2, v3};
+    } else {
+        if (FMT == 1) {
+            v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
+            v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
+            v2 = __builtin_amdgcn_fmed3f(v2, -65504.0f, 65504.0f);
+            v3 = __builtin_amdgcn_fmed3f(v3, -65504.0f, 65504.0f);
+        }
+#pragma unroll
+        for (int t = 0; t < OT; t++) {
+            const unsigned p01 = FMT ? pk_f16(v0, v1) : pk_bf16(v0, v1), p23 = FMT ? pk_f16(v2, v3) : pk_bf16(v2, v3);
+            *(__attribute__((address_space(1))) u32x2 *)(base + (long long)t * ts_bytes) = (u32x2){p01, p23};
+            if (t + 1 < OT) {   // exact residuals: |v - round(v)| fits fp32
+                if (FMT) {
+                    const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
+                    const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
+                    v0 -= b01[0]; v1 -= b01[1]; v2 -= b23[0]; v3 -= b23[1];
+                } else {
+                    v0 -= __uint_as_float(p01 << 16);
+                    v1 -= __uint_as_float(p01 & 0xFFFF0000u);
+                    v2 -= __uint_as_float(p23 << 16);
+                    v3 -= __uint_as_float(p23 & 0xFFFF0000u);
+                }
+            }
+        }
+    }
+}
 template <int OT, int FMT>
 static __device__ __forceinline__ void store_terms(float *out, long long elem_off, long long out_ts, float v0, float v1, float v2, float v3)
 {
@@ -211,15 +249,26 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     if (tile >= chunk_end) return;
 
     // bias[COUT] sits behind the weight ring; lane (li, kk) reads the 4 channels of a register quad as one b128
+    // 8-wave shapes (accumulators in VGPRs, two waves per SIMD): the accumulators START at the bias -- a ds_read_b128 per register
+    // quad straight into the accumulator registers replaces a v_mov to zero them plus a v_add in the epilogue, 2 of the 4.5 VALU
+    // instructions per element of an epilogue that both waves of a SIMD reach together.  fp16 weights are pre-scaled by
+    // S = 1 / acc_scale (a power of two): the bias is too.  The 4-wave shapes keep their accumulators in AGPRs (zeroed for free by the
+    // first MFMA of a tile, and a load would need a v_accvgpr_write per register): they add the bias in the epilogue as before.
+    constexpr bool BINIT = (NW == 8);
     constexpr unsigned BIAS_BASE = B_BASE + RING * B_BYTES;
-    for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c];   // visible after the prologue barrier
+    {
+        const float bmul = (BINIT && FMT) ? 1.0f / d.acc_scale : 1.0f;
+        for (int c = threadIdx.x; c < COUT; c += NW * 64) lds[BIAS_BASE / 4 + c] = d.bias[c] * bmul;   // visible after the prologue barrier
+    }
     // OT == 9 (last layer fused into this epilogue): its weights as MFMA A fragments, [term][plane block][k-group][lane][8]
+    // LT = terms of the fused product: 1 (one product) in the one-term mode, 2 (3 products) in the two-term modes, 3 (6) for BF16X3.
+    constexpr int LT = T == 3 ? 3 : T == 1 ? 1 : 2;
     constexpr unsigned W7_BASE = BIAS_BASE + COUT * 4;
-    constexpr bool W7_IN_LDS = (T == 2 && E == 1);   // (the one-term and 8-slot shapes have no LDS left: fragments come from L2 instead)
+    constexpr bool W7_IN_LDS = (T == 2 && E == 1) || T == 1;   // (the three-term and two-term 8-slot shapes have no LDS left: fragments come from L2)
     if constexpr (OT == 9 && W7_IN_LDS) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(d.w7pk);
         u32x4 *dst = reinterpret_cast<u32x4 *>(const_cast<char *>(ldsb) + W7_BASE);
-        for (int i = threadIdx.x; i < 2 * NBT * 2 * 64; i += NW * 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < LT * NBT * 2 * 64; i += NW * 64) dst[i] = src[i];
     }
 
     // ---- per-lane DMA source offsets of the A halo tile, in 16-byte units (8 bf16) ----
@@ -295,12 +344,40 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
     };
 
     f32x16 acc[MB][NB];
+    // C/D layout: lane&31 = pixel, register r = channel 32*nb + (r&3) + 8*(r>>2) + 4*(lane>>5): quad i = r>>2 is one b128 of the bias
+    auto acc_init = [&]() {
 #pragma unroll
-    for (int mb = 0; mb < MB; mb++)
+        for (int mb = 0; mb < MB; mb++) {
+            if constexpr (BINIT) {
+                unsigned bo = BIAS_BASE + (unsigned)(nb0 * 32 + 4 * kk) * 4;
+                asm volatile("" : "+v"(bo));   // one read per quad, landing in the accumulator registers (no shared copy + v_mov)
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
+                for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+                    for (int i = 0; i < 4; i++) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + bo + (nb * 32 + 8 * i) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[mb][nb][4 * i + e] = bq[e];
+                    }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[mb][nb][r] = 0.0f;
+            }
+        }
+    };
+    // bias + LeakyReLU of one accumulator register; b = its bias (used by the 4-wave shapes only)
+    auto act = [&](float a, float b) -> float {
+        // fp16 weights (and the bias an 8-wave accumulator started at) are pre-scaled by a power of two: undo it, exactly
+        const float s = FMT ? a * d.acc_scale : a;
+        if constexpr (BINIT) return leaky_acc(s);
+        else { const float sb = s + b; return fmaxf(sb, 0.1f * sb); }
+    };
+    auto bias_quad = [&](int nb, int i) -> f32x4 {
+        if constexpr (BINIT) return (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        else return *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
+    };
 
     // ---- prologue: A(slice 0) and B stages 0..LEAD-1 of the first tile ----
     tile_offsets(tile);
@@ -312,6 +389,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
         for (int jb = 0; jb < BPW; jb++) dma_b(0, t, t, jb);
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
+    acc_init();
 
     unsigned gs = 0;      // ring slot of the current stage
     unsigned abuf = 0;    // A buffer of the current slice
@@ -469,6 +547,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             //   t*ts + (c / 16)*gs + y*rs + x*16 + c % 16   (the layout the next layer's A tiles stream from)
             const long long obase = OT == 0 ? (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * COUT + nb0 * 32 + 4 * kk
                                             : (long long)(oy0 + wm * MB) * d.out_rs + (long long)(ox0 + li) * GRP;
+            constexpr int OES = OT == 0 ? 4 : 2;                                              // bytes per stored element
+            const unsigned lane_ob = (unsigned)(OT == 0 ? li * COUT + 4 * kk : li * GRP + 4 * kk) * OES;   // this lane's byte offset inside the tile
             auto oofs = [&](int mb, int nb, int i) -> long long {   // element offset of channels (nb0+nb)*32 + 8i + 4kk .. +3
                 if (OT == 0) return obase + (long long)mb * d.out_rs + nb * 32 + 8 * i;
                 const int c = (nb0 + nb) * 32 + 8 * i + 4 * kk;
@@ -480,11 +560,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 // The accumulator registers already ARE a B operand: lane (pixel, kk), registers 8h .. 8h+7 of a plane
                 // block hold 8 of the 16 channels of k-group h (16h + 4kk + {0..3, 8..11}); the weight fragments were
                 // packed with the same channel order.  Activations are split into two terms exactly like stored
-                // ones (two terms also in the one-term mode: the fp32 accumulators are at hand); same product lists as the
+                // ones (one term in the one-term mode: W2XC_PRECISION_BF16 means bf16 operands everywhere); same product lists as the
                 // main loop.  Each wave column (wn) writes its partial G as 9 tap planes
                 // [half][tap][y][x] (128-byte runs per store) and conv3x3_last_gather adds the halves and the taps.
-                // LT = terms of the fused product: 2 (3 products) for the one- and two-term modes, 3 (6 products) for BF16X3.
-                constexpr int LT = T == 3 ? 3 : 2;
                 u32x4 w7[LT][NB][2];
 #pragma unroll
                 for (int t = 0; t < LT; t++)
@@ -508,15 +586,12 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                             float a[8];
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
-                                const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 16 * h + 8 * q + 4 * kk) * 4);
+                                const f32x4 bq = bias_quad(nb, 2 * h + q);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
-                                    const int r = 8 * h + 4 * q + e;
-                                    const float s = (FMT ? acc[mb][nb][r] * d.acc_scale : acc[mb][nb][r]) + bq[e];
-                                    float v = fmaxf(s, 0.1f * s);
+                                    float v = act(acc[mb][nb][8 * h + 4 * q + e], bq[e]);
                                     if (FMT) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
                                     a[4 * q + e] = v;
-                                    acc[mb][nb][r] = 0.0f;
                                 }
                             }
                             u32x4 xt[LT];   // activation terms of this k-group as B operands
@@ -558,23 +633,30 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 }
                 epi_stores = interior;
             } else if (interior) {
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
+                gbyte_t *lp = nullptr;
+                static_for<0, MB * NB * 4>([&](auto IDX) {
+                            constexpr int mb = decltype(IDX)::value / (NB * 4), nb = (decltype(IDX)::value / 4) % NB, i = decltype(IDX)::value % 4;
                             float v[4];
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
+                            const f32x4 bq = bias_quad(nb, i);
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
-                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bq[e];
-                                v[e] = fmaxf(s, 0.1f * s);
-                                acc[mb][nb][4 * i + e] = 0.0f;
+                            for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
+                            if constexpr (NW == 8) {
+                                // 256 registers per wave: a wave-uniform 64-bit base from the scalar ALU per (row, 16-plane group) + one lane
+                                // offset, instead of 64-bit per-lane bases that spill (4-wave shapes: per-lane bases + immediates, as before)
+                                constexpr bool newbase = OT == 0 ? (i == 0) : ((i & 1) == 0);
+                                if constexpr (newbase) {
+                                    const long long uo = OT == 0 ? (long long)(oy0 + wm * MB + mb) * d.out_rs + (long long)ox0 * COUT + (nb0 + nb) * 32
+                                                                 : (long long)(oy0 + wm * MB + mb) * d.out_rs + (long long)ox0 * GRP +
+                                                                       (long long)((nb0 + nb) * 2 + (i >> 1)) * d.out_gs;
+                                    gbyte_t *ub = (gbyte_t *)(reinterpret_cast<char *>(d.out)) + uo * OES;
+                                    asm volatile("" : "+s"(ub));   // (keeps the scalar base apart from the lane offset through instruction selection)
+                                    lp = ub + lane_ob;
+                                }
+                                store_terms_at<OT, FMT>(lp + (OT == 0 ? 32 * i : 16 * (i & 1)), d.out_ts * OES, v[0], v[1], v[2], v[3]);
+                            } else {
+                                store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
                             }
-                            store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
-                        }
+                });
                 epi_stores = true;
             } else {
                 const bool xin = ox0 + li < d.out_w;
@@ -586,20 +668,16 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             float v[4];
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
+                            const f32x4 bq = bias_quad(nb, i);
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                // fp16 weights are pre-scaled by a power of two (w2xc_split_pack): undo it, exactly
-                                const float s = (FMT ? acc[mb][nb][4 * i + e] * d.acc_scale : acc[mb][nb][4 * i + e]) + bq[e];
-                                v[e] = fmaxf(s, 0.1f * s);
-                                acc[mb][nb][4 * i + e] = 0.0f;
-                            }
+                            for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
                             if (in) store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
                         }
                 }
             }
             tile += per;
             if (tile >= chunk_end) break;
+            acc_init();
             sl = 0;
         } else {
             sl++;
@@ -776,13 +854,24 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
     __syncthreads();
 
     // ---- 3. layer 2 ----
+    // same arithmetic as the conv3x3_split shape that runs this layer unfused (bit-identical results): its 8-wave shapes
+    // (two terms, 64 / 128 planes) start the accumulators at the pre-scaled bias, the 4-wave ones add the bias in the epilogue
+    constexpr bool BINIT = (T == 2 && COUT >= 64);
     f32x16 acc2[MB][NBT];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
+    {
+        const float bmul = FMT ? 1.0f / d.acc_scale : 1.0f;
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc2[mb][nb][r] = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (BINIT) bq = *reinterpret_cast<const f32x4 *>(d.bias + nb * 32 + 8 * i + 4 * kk);
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc2[mb][nb][4 * i + e] = BINIT ? bq[e] * bmul : 0.0f;
+            }
+    }
     // 18 (k-group, tap) iterations in conv3x3_split's stage order; the weight fragments come straight from L2, loaded
     // PF iterations ahead into a rotating register queue (the loops are fully unrolled: all indices are constants)
     const u32x4 *w2 = reinterpret_cast<const u32x4 *>(d.wpk) + lane;
@@ -851,12 +940,14 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int c = nb * 32 + 8 * i + 4 * kk;
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(d.bias + c);
                 float v[4];
+                f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (!BINIT) bq = *reinterpret_cast<const f32x4 *>(d.bias + c);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float sacc = (FMT ? acc2[mb][nb][4 * i + e] * d.acc_scale : acc2[mb][nb][4 * i + e]) + bq[e];
-                    v[e] = fmaxf(sacc, 0.1f * sacc);
+                    const float sacc = FMT ? acc2[mb][nb][4 * i + e] * d.acc_scale : acc2[mb][nb][4 * i + e];
+                    if constexpr (BINIT) v[e] = leaky_acc(sacc);
+                    else { const float sb = sacc + bq[e]; v[e] = fmaxf(sb, 0.1f * sb); }
                 }
                 const long long o = OT == 0 ? (long long)y * d.out_rs + (long long)x * COUT + c
                                             : (long long)(c / 16) * d.out_gs + (long long)y * d.out_rs + (long long)x * 16 + c % 16;
@@ -1029,7 +1120,7 @@ static hipError_t launch_split(const W2xcConvDesc &d, hipStream_t stream)
     constexpr int NW = WM * WN;
     constexpr int A_PIECES = T * NPIXP * 2 * KG / 64, APW = (A_PIECES + NW - 1) / NW;
     constexpr size_t lds_bytes = 2 * (size_t)(NW * APW * 1024) + (size_t)RING * (T * KG * (COUT / 32) * 1024) + COUT * 4 +
-                                 ((OT == 9 && T == 2 && E == 1) ? 4 * (COUT / 32) * 1024 : 0);
+                                 ((OT == 9 && T == 2 && E == 1) ? 4 * (COUT / 32) * 1024 : (OT == 9 && T == 1) ? 2 * (COUT / 32) * 1024 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_split<CIN, COUT, MB, NB, WM, WN, T, OT, KG, RING, FMT, E>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
