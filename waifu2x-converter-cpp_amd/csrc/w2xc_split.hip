@@ -374,10 +374,16 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
         if constexpr (BINIT) return leaky_acc(s);
         else { const float sb = s + b; return fmaxf(sb, 0.1f * sb); }
     };
-    auto bias_quad = [&](int nb, int i) -> f32x4 {
-        if constexpr (BINIT) return (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        else return *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + ((nb0 + nb) * 32 + 8 * i + 4 * kk) * 4);
-    };
+    // 4-wave shapes: the bias quads of this wave's planes live in registers for the whole kernel (up to 512 per wave there).  Reading
+    // them from LDS in the epilogue put an exposed ds_read -> s_waitcnt round trip in front of every quad: 3-4k cycles per tile,
+    // 42 % of the one-term 32->64 tile (s_memtime, round 2).
+    f32x4 bqr[BINIT ? 1 : NB][4];
+    if constexpr (!BINIT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) bqr[nb][i] = *reinterpret_cast<const f32x4 *>(d.bias + (nb0 + nb) * 32 + 8 * i + 4 * kk);
+    }
 
     // ---- prologue: A(slice 0) and B stages 0..LEAD-1 of the first tile ----
     tile_offsets(tile);
@@ -586,7 +592,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                             float a[8];
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
-                                const f32x4 bq = bias_quad(nb, 2 * h + q);
+                                const f32x4 bq = bqr[BINIT ? 0 : nb][2 * h + q];   // (unused by the 8-wave shapes)
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
                                     float v = act(acc[mb][nb][8 * h + 4 * q + e], bq[e]);
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                 static_for<0, MB * NB * 4>([&](auto IDX) {
                             constexpr int mb = decltype(IDX)::value / (NB * 4), nb = (decltype(IDX)::value / 4) % NB, i = decltype(IDX)::value % 4;
                             float v[4];
-                            const f32x4 bq = bias_quad(nb, i);
+                            const f32x4 bq = bqr[BINIT ? 0 : nb][i];   // (unused by the 8-wave shapes)
 #pragma unroll
                             for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
                             if constexpr (NW == 8) {
@@ -668,7 +674,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             float v[4];
-                            const f32x4 bq = bias_quad(nb, i);
+                            const f32x4 bq = bqr[BINIT ? 0 : nb][i];   // (unused by the 8-wave shapes)
 #pragma unroll
                             for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
                             if (in) store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
@@ -1158,6 +1164,9 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         //   64->64    8 rows, 4 waves, 64-channel stages, ring of 8 instead of 4: 0.74 -> 0.67 ms.  A stage of these kernels lasts
         //             0.5-1k cycles, so with a ring of 4 a weight stage is awaited ONE stage (< 0.5 us) after its issue -- less than
         //             an L2 round trip under load; 8 slots put 5 stages between issue and use.  (32->64 also runs a ring of 8.)
+        //             Then 16 rows, 8 waves of 4 rows x 32 planes (4x1 blocks), 32-channel stages, ring of 8: 0.645 -> 0.60 ms (8 rows on
+        //             8 waves of 2x1 blocks: the same).  One wave per SIMD hands the matrix pipe an MFMA every ~40 cycles, two every ~33
+        //             (s_memtime); the same 8-wave shape on 32->64 measured equal to the 4-wave one (that layer is HBM-bound).
         //   64->128   8 rows, 8 waves (2x2 blocks), 32-channel stages, ring of 12 with one barrier per 3 taps (LOOK = 5 stages between
         //             a weight stage's issue and its use): 1.28 -> 1.16 ms.  (Its 64-channel stages are 16 KiB -- a ring of 4 is all
         //             that fits; the 16-row forms measured 4-15 % slower; 4x4 blocks for 128 planes spill ~290 registers.)
@@ -1168,7 +1177,7 @@ static hipError_t launch_split_t(const W2xcConvDesc &d, hipStream_t stream)
         case 32064:  return launch_split<32, 64, 4, 2, 4, 1, 1, OT, 2, 8, FMT>(d, stream);
         case 32128:  return launch_split<32, 128, 4, 2, 2, 2, 1, OT, 2, 4, FMT>(d, stream);
         case 64032:  return launch_split<64, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
-        case 64064:  return launch_split<64, 64, 2, 2, 4, 1, 1, OT, 4, 8, FMT>(d, stream);
+        case 64064:  return launch_split<64, 64, 4, 1, 4, 2, 1, OT, 2, 8, FMT>(d, stream);
         case 64128:  return launch_split<64, 128, 2, 2, 4, 2, 1, OT, 2, 12, FMT, 3>(d, stream);
         case 128032: return launch_split<128, 32, 2, 1, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
         case 128064: return launch_split<128, 64, 2, 2, 4, 1, 1, OT, 4, 4, FMT>(d, stream);
