@@ -69,6 +69,16 @@ static __device__ __forceinline__ unsigned pk_f16(float a, float b)
 // prove quiet; v_med3_f32 has no such requirement.)
 static __device__ __forceinline__ float leaky_acc(float s) { return __builtin_amdgcn_fmed3f(s, 0.1f * s, 3.402823466e+38f); }   // (FLT_MAX: with +inf the compiler folds it back to fmaxf)
 
+// v - (float)h for an fp16 h: one v_fma_mix_f32 (the conversion rides in the instruction) instead of v_cvt_f32_f16 + v_sub_f32; exact either way
+// (HI = 0 / 1: the low / high half of the packed pair p.  The compiler folds fma(fpext(h), -1, v) back into the two-instruction form.)
+template <int HI> static __device__ __forceinline__ float sub_f16(float v, unsigned p)
+{
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
+    return r;
+}
+
 // Store 4 consecutive channels of one pixel as OT term planes (OT >= 1) or as fp32 (OT == 0).
 // FMT = 0: bf16 terms (same exponent range as fp32).  FMT = 1: fp16 terms -- values are clamped to the fp16
 // range (+-65504) first; residuals below 2^-14 are held to 2^-25 absolute by fp16's subnormals.
@@ -92,9 +102,7 @@ static __device__ __forceinline__ void store_terms_at(gbyte_t *base, long long t
             *(__attribute__((address_space(1))) u32x2 *)(base + (long long)t * ts_bytes) = (u32x2){p01, p23};
             if (t + 1 < OT) {   // exact residuals: |v - round(v)| fits fp32
                 if (FMT) {
-                    const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
-                    const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
-                    v0 -= b01[0]; v1 -= b01[1]; v2 -= b23[0]; v3 -= b23[1];
+                    v0 = sub_f16<0>(v0, p01); v1 = sub_f16<1>(v1, p01); v2 = sub_f16<0>(v2, p23); v3 = sub_f16<1>(v3, p23);
                 } else {
                     v0 -= __uint_as_float(p01 << 16);
                     v1 -= __uint_as_float(p01 & 0xFFFF0000u);
@@ -124,9 +132,7 @@ static __device__ __forceinline__ void store_terms(float *out, long long elem_of
             *reinterpret_cast<u32x2 *>(o16 + (long long)t * out_ts) = (u32x2){p01, p23};
             if (t + 1 < OT) {   // exact residuals: |v - round(v)| fits fp32
                 if (FMT) {
-                    const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
-                    const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
-                    v0 -= b01[0]; v1 -= b01[1]; v2 -= b23[0]; v3 -= b23[1];
+                    v0 = sub_f16<0>(v0, p01); v1 = sub_f16<1>(v1, p01); v2 = sub_f16<0>(v2, p23); v3 = sub_f16<1>(v3, p23);
                 } else {
                     v0 -= __uint_as_float(p01 << 16);
                     v1 -= __uint_as_float(p01 & 0xFFFF0000u);
@@ -374,6 +380,11 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
         if constexpr (BINIT) return leaky_acc(s);
         else { const float sb = s + b; return fmaxf(sb, 0.1f * sb); }
     };
+    // the same for a register quad.  (Packed v_pk_mul_f32 for the two multiplies of an element pair measured 0.5 % slower on the one-term
+    // shapes and equal on the two-term ones: packed fp32 VALU beside the partner wave's MFMAs is no gain.)
+    auto act4 = [&](float a0, float a1, float a2, float a3, const f32x4 &bq, float (&v)[4]) {
+        v[0] = act(a0, bq[0]); v[1] = act(a1, bq[1]); v[2] = act(a2, bq[2]); v[3] = act(a3, bq[3]);
+    };
     // 4-wave shapes: the bias quads of this wave's planes live in registers for the whole kernel (up to 512 per wave there).  Reading
     // them from LDS in the epilogue put an exposed ds_read -> s_waitcnt round trip in front of every quad: 3-4k cycles per tile,
     // 42 % of the one-term 32->64 tile (s_memtime, round 2).
@@ -593,12 +604,10 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
                                 const f32x4 bq = bqr[BINIT ? 0 : nb][2 * h + q];   // (unused by the 8-wave shapes)
+                                float v4[4];
+                                act4(acc[mb][nb][8 * h + 4 * q], acc[mb][nb][8 * h + 4 * q + 1], acc[mb][nb][8 * h + 4 * q + 2], acc[mb][nb][8 * h + 4 * q + 3], bq, v4);
 #pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    float v = act(acc[mb][nb][8 * h + 4 * q + e], bq[e]);
-                                    if (FMT) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-                                    a[4 * q + e] = v;
-                                }
+                                for (int e = 0; e < 4; e++) a[4 * q + e] = FMT ? __builtin_amdgcn_fmed3f(v4[e], -65504.0f, 65504.0f) : v4[e];
                             }
                             u32x4 xt[LT];   // activation terms of this k-group as B operands
 #pragma unroll
@@ -609,9 +618,8 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                                     xt[t][u] = ph;
                                     if (t + 1 < LT) {
                                         if (FMT) {
-                                            const f32x2 b = __builtin_convertvector(__builtin_bit_cast(h16x2_t, ph), f32x2);
-                                            a[2 * u] -= b[0];
-                                            a[2 * u + 1] -= b[1];
+                                            a[2 * u] = sub_f16<0>(a[2 * u], ph);
+                                            a[2 * u + 1] = sub_f16<1>(a[2 * u + 1], ph);
                                         } else {
                                             a[2 * u] -= __uint_as_float(ph << 16);
                                             a[2 * u + 1] -= __uint_as_float(ph & 0xFFFF0000u);
@@ -644,8 +652,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                             constexpr int mb = decltype(IDX)::value / (NB * 4), nb = (decltype(IDX)::value / 4) % NB, i = decltype(IDX)::value % 4;
                             float v[4];
                             const f32x4 bq = bqr[BINIT ? 0 : nb][i];   // (unused by the 8-wave shapes)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
+                            act4(acc[mb][nb][4 * i], acc[mb][nb][4 * i + 1], acc[mb][nb][4 * i + 2], acc[mb][nb][4 * i + 3], bq, v);
                             if constexpr (NW == 8) {
                                 // 256 registers per wave: a wave-uniform 64-bit base from the scalar ALU per (row, 16-plane group) + one lane
                                 // offset, instead of 64-bit per-lane bases that spill (4-wave shapes: per-lane bases + immediates, as before)
@@ -675,8 +682,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
                         for (int i = 0; i < 4; i++) {
                             float v[4];
                             const f32x4 bq = bqr[BINIT ? 0 : nb][i];   // (unused by the 8-wave shapes)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = act(acc[mb][nb][4 * i + e], bq[e]);
+                            act4(acc[mb][nb][4 * i], acc[mb][nb][4 * i + 1], acc[mb][nb][4 * i + 2], acc[mb][nb][4 * i + 3], bq, v);
                             if (in) store_terms<OT, FMT>(d.out, oofs(mb, nb, i), d.out_ts, v[0], v[1], v[2], v[3]);
                         }
                 }
@@ -845,9 +851,7 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
                 *reinterpret_cast<u32x2 *>(ldsb + pbase + t * ACT_TERM + (((unsigned)c4 ^ sw) << 4)) = (u32x2){p01, p23};
                 if (t + 1 < T) {
                     if (FMT) {
-                        const f32x2 b01 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p01), f32x2);
-                        const f32x2 b23 = __builtin_convertvector(__builtin_bit_cast(h16x2_t, p23), f32x2);
-                        q[0] -= b01[0]; q[1] -= b01[1]; q[2] -= b23[0]; q[3] -= b23[1];
+                        q[0] = sub_f16<0>(q[0], p01); q[1] = sub_f16<1>(q[1], p01); q[2] = sub_f16<0>(q[2], p23); q[3] = sub_f16<1>(q[3], p23);
                     } else {
                         q[0] -= __uint_as_float(p01 << 16);
                         q[1] -= __uint_as_float(p01 & 0xFFFF0000u);
