@@ -40,7 +40,7 @@ typedef struct w2xc_model w2xc_model;
 #define W2XC_PRECISION_BF16 1   /* w2xc_convert_* only: activations BETWEEN layers are bf16 (RNE), layers
                                  * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
                                  * accumulate, bias and LeakyReLU; the first layer stays fp32, a one-plane
-                                 * last layer is fused into layer n-1 with 16-bit-accurate split products.
+                                 * last layer is fused into layer n-1's epilogue as one more bf16 layer.
                                  * Not the reference's arithmetic: tolerance in DESIGN.md 4.          */
 #define W2XC_PRECISION_BF16X2 2 /* w2xc_convert_* only: split products.  Every fp32 activation / weight of layers
                                  * 2..n-1 is carried as the sum of 2 bf16 terms (hi + lo, ~16 mantissa bits)
