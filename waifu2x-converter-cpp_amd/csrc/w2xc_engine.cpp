@@ -78,6 +78,7 @@ struct DevLayer {
     W2xcKernelKind fast = W2XC_K_DIRECT;
     float *w_fast = nullptr;
     float *w_direct = nullptr;
+    float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path), packed on first use
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
@@ -170,6 +171,7 @@ struct DevCtx {
         for (auto &l : layers) {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
+            if (l.w_wino) hipFree(l.w_wino);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
             for (float *p : l.w_last_fused)
@@ -387,6 +389,14 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
     return W2XC_OK;
 }
 
+// fp32 path: Winograd F(2x2,3x3) for the shapes conv3x3_wino covers (W2XC_WINOGRAD=0 keeps conv3x3_mfma2 everywhere)
+bool wino_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("W2XC_WINOGRAD"); v = e ? (atoi(e) != 0) : 0; }
+    return v != 0;
+}
+
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, bool profile)
 {
     DevLayer &dl = c->layers[l];
@@ -426,6 +436,16 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
+    const bool wino = kind == W2XC_K_MFMA && wino_enabled() && w2xc_wino_supported(d.cin, d.cout);
+    if (wino) {
+        if (!dl.w_wino) {
+            std::vector<float> pk(w2xc_wino_packed_floats(d.cin, d.cout));
+            w2xc_wino_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
+            int rc = upload(pk, &dl.w_wino);
+            if (rc) return rc;
+        }
+        d.wpk = dl.w_wino;
+    }
     d.bias = dl.bias;
     ProfEvent ev;
     if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
@@ -433,6 +453,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                    : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
+                   : wino                        ? w2xc_launch_wino(d, st)
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -565,6 +586,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.out_w = w + 2 * (n - k);
             d.off_y = k == 1 ? (y0 - n - vy0) : 0;
             d.off_x = k == 1 ? -n : 0;
+            d.wino_py = (y0 - (n - k)) & 1;   // parity of this launch's first output row in the coordinates of the whole plane
             d.in_shift = k == 1 ? up : 0;
             const W2xcKernelKind kind = layer_kind(m, k - 1, o);
             if (kind == W2XC_K_FUSED_AWAY) {   // layer 1 inside layer 2's kernel: keep its input description for that launch
@@ -1859,7 +1881,9 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
 {
     if (!m || layer < 0 || layer >= (int)m->layers.size()) return "";
     const w2xc_opts o = resolve_opts(opts);
-    return w2xc_kernel_name(layer_kind(m, layer, o), m->layers[layer].nin, m->layers[layer].nout);
+    const W2xcKernelKind k = layer_kind(m, layer, o);
+    if (k == W2XC_K_MFMA && wino_enabled() && w2xc_wino_supported(m->layers[layer].nin, m->layers[layer].nout)) return "conv3x3_wino";
+    return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
 }
 
 }  // extern "C"

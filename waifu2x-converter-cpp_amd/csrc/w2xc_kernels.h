@@ -42,6 +42,9 @@ struct W2xcConvDesc {
     const void *w7pk;    // last layer's weights as MFMA A fragments (w2xc_split_pack_last)
     float g_scale;       // fp16: 1 / (power-of-two scale of the last layer's weights)
     int halves;
+    // conv3x3_wino: 0 / 1 = the 2x2 output blocks start at row -wino_py of this launch's region, so that they sit on EVEN rows of the
+    // layer's whole output whatever row the band starts at -- a pixel's arithmetic then does not depend on the banding.
+    int wino_py;
 };
 
 enum W2xcKernelKind {
@@ -68,6 +71,13 @@ void w2xc_pack_weights(W2xcKernelKind kind, int cin, int cout, const float *w, f
 
 // Enqueue one layer on `stream`.  Returns hipSuccess or the launch error.
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream);
+
+// Winograd F(2x2, 3x3) on the fp32 MFMA (w2xc_wino.hip): the same layer as W2XC_K_MFMA (NHWC fp32 in / out) with 2.25x fewer MFMAs,
+// for the shapes w2xc_wino_supported() names; d.wpk = the w2xc_wino_pack image (16 * cin * cout floats).
+bool w2xc_wino_supported(int cin, int cout);
+size_t w2xc_wino_packed_floats(int cin, int cout);
+void w2xc_wino_pack(int cin, int cout, const float *w, float *dst);
+hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
 
 // split kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` 16-bit terms of every weight in
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.
