@@ -78,11 +78,29 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
         const int rem = pp - row * HW;
         col = rem < 17 ? 2 * rem : 2 * (rem - 17) + 1;
     };
-    // (recomputed per item rather than kept as tile-independent offsets + base: 10 registers matter more here than ~150 VALU per 65k cycles)
+    // tile-independent part of the offsets (interior tiles: + one base): per-lane constants, parked in LDS (10 KiB behind the U ring)
+    // rather than in 10 registers -- the stage needs every VGPR, and the clamped path costs ~10k cycles per item when taken each time
+    constexpr unsigned LOFS_BASE = B_BASE + 2 * B_BYTES;
+    {
+        unsigned *lofs = reinterpret_cast<unsigned *>(const_cast<char *>(ldsb) + LOFS_BASE);
+#pragma unroll
+        for (int jj = 0; jj < APW; jj++) {
+            int row, col, q;
+            slot_of(jj, row, col, q);
+            lofs[jj * 256 + threadIdx.x] = (unsigned)(((long long)row * d.in_rs + (long long)col * CIN) >> 2) + q;
+        }
+    }
     auto tile_offsets = [&](int it) {
         const int pt = it / NOB;
         const int ty_ = pt / tiles_x, tx_ = pt - ty_ * tiles_x;
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
+        if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
+            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * CIN) >> 2);
+            const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
+#pragma unroll
+            for (int jj = 0; jj < APW; jj++) goff[jj] = lofs[jj * 256 + threadIdx.x] + base;
+            return;
+        }
 #pragma unroll
         for (int jj = 0; jj < APW; jj++) {
             int row, col, q;
@@ -131,7 +149,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     __builtin_amdgcn_s_barrier();
 
     unsigned abuf = 0, bbuf = 0;
+#ifdef W2XC_DBG_TIMING
+    unsigned long long T_st = 0, T_epi = 0, T0 = __builtin_amdgcn_s_memtime(); int n_it = 0;
+#endif
     for (;;) {
+#ifdef W2XC_DBG_TIMING
+      const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
       // The accumulators are DEFINED by the first stage of an item (its first 16 MFMAs take C = 0) and die in the epilogue: carried
       // across items they are 256 loop-carried registers whose phi copies the allocator routes through VGPRs and scratch.
       f32x16 acc[16];
@@ -240,6 +264,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
       stage(std::true_type{}, 0);
 #pragma unroll 1
       for (int sl = 1; sl < NSL; sl++) stage(std::false_type{}, sl);
+#ifdef W2XC_DBG_TIMING
+      const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+      T_st += t_b - t_a;
+#endif
         {
             // the hazard recogniser does not see inside inline asm: let the last MFMAs drain (16 passes) before VALU reads their results
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -249,6 +277,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             const int tile_y = pt / tiles_x, tile_x = pt - tile_y * tiles_x;
             const int oy = tile_y * ROWS - d.wino_py + 4 * wave + 2 * tyl, ox = tile_x * 32 + 2 * tx;
             float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * kk;
+            const int ty0 = tile_y * ROWS - d.wino_py;
+            const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
                 const f32x4 bq = *reinterpret_cast<const f32x4 *>(d.bias + ob * 32 + 8 * q4 + 4 * kk);
@@ -270,17 +300,31 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
                         y[i][1][e] = fmaxf(y1, 0.1f * y1);
                     }
                 }
+                if (interior) {
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                    for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w)
-                            *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 8 * q4) = y[i][j];
+                        for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 8 * q4) = y[i][j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+                            if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w)
+                                *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 8 * q4) = y[i][j];
+                }
             }
+#ifdef W2XC_DBG_TIMING
+            T_epi += __builtin_amdgcn_s_memtime() - t_b; n_it++;
+#endif
             item += per;
             if (item >= chunk_end) break;
         }
     }
+#ifdef W2XC_DBG_TIMING
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        printf("TIMING wino %d->%d wave %d: items %d stages %llu epi %llu total %llu cycles\n", CIN, COUT, (int)(threadIdx.x >> 6), n_it, T_st, T_epi, __builtin_amdgcn_s_memtime() - T0);
+#endif
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
 }
 
@@ -320,7 +364,7 @@ static hipError_t launch_wino(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 1) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 32);
-    constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024);
+    constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024) + 10 * 1024;   // tile + U ring + the DMA offset table
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_wino<CIN, COUT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
