@@ -210,41 +210,48 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
         for (int k = 0; k < 4; k++) transform_cols(std::integral_constant<int, 0>{}, k);
 #pragma unroll
         for (int k = 0; k < 4; k++) transform_rows(v_c, k);
+        auto load_raw1 = [&](int G, int r, int c) {
+            raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(ldsb + abuf * A_BYTES + (a1[r][c] ^ (unsigned)((G >> 1) << 4)) + 8 * (G & 1));
+        };
+        auto load_u1 = [&](int q, int G, int s) {
+            u_n[q] = *reinterpret_cast<const f32x4 *>(ldsb + B_BASE + bbuf * B_BYTES + (((G * 2 + s) * 4 + q) * 64 + lane) * 16);
+        };
         static_for<0, 8>([&](auto TT) {
             constexpr int t8 = decltype(TT)::value, G = t8 >> 1, s = t8 & 1;
-            // Every non-MFMA instruction is pinned into the shadow of one of the step's 16 MFMAs (left alone, the scheduler hoists
-            // the fragment reads of the whole stage to its top and spills ~300 registers):
-            //   behind MFMA 0: the 4 x b128 of U for the NEXT step; at odd steps also the 16 x b64 of the next k-group's patch (the
-            //                  patch registers are free: the even step consumed the second channel of the current k-group)
-            //   behind MFMAs 2, 7, 12: one transfer of the next stage each (10 tile pieces + 8 U pieces over the 8 steps)
-            //   behind MFMAs 6 .. 13: the input transform of the next step, 4 of its 32 additions each
+            // Every non-MFMA instruction is pinned into the shadow of one of the step's 16 MFMAs, a FEW per MFMA (a wave issues in order:
+            // the 20 fragment reads of a step behind ONE MFMA held the next MFMA back 350-500 cycles, s_memtime per step):
+            //   behind MFMAs 0..7  (odd steps) the patch of the next k-group, two b64 reads each, column by column
+            //   behind MFMAs 8..11 one b128 of the next step's U and one column of its input transform (4 additions)
+            //   behind MFMAs 12..15 one row of the input transform (4 additions)
+            //   behind MFMAs 1, 6, 11 one transfer of the next stage (10 tile pieces + 8 U pieces over the 8 steps)
             static_for<0, 16>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                // (inline asm with the accumulator tied to an AGPR tuple: through the builtin the register allocator, 256 accumulator
-                //  registers deep, shuttles them between AGPRs, VGPRs and scratch around the loop header -- ~100 reloads per stage)
                 if constexpr (first && t8 == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
                 else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (xi == 0 && t8 < 7) {
-                    load_u(u_n, (t8 + 1) >> 1, (t8 + 1) & 1);
-                    if constexpr (s == 1) load_raw(G + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (t8 < 7) {
+                    if constexpr (xi < 8 && s == 1) {   // (the patch registers are free: the even step consumed the second channel)
+                        load_raw1(G + 1, (2 * xi) & 3, xi >> 1);
+                        load_raw1(G + 1, (2 * xi + 1) & 3, xi >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (xi >= 8 && xi < 12) {
+                        load_u1(xi - 8, (t8 + 1) >> 1, (t8 + 1) & 1);
+                        if constexpr (s == 0) transform_cols(std::integral_constant<int, 1>{}, xi - 8);
+                        else transform_cols(std::integral_constant<int, 0>{}, xi - 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (xi >= 12) {
+                        transform_rows(v_n, xi - 12);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                constexpr int q = t8 * 3 + (xi == 2 ? 0 : xi == 7 ? 1 : xi == 12 ? 2 : -100);
+                constexpr int q = t8 * 3 + (xi == 1 ? 0 : xi == 6 ? 1 : xi == 11 ? 2 : -100);
                 if constexpr (q >= 0 && q < APW) {
                     dma_a(a_add, abuf ^ 1u, q);
                     __builtin_amdgcn_sched_barrier(0);
                 } else if constexpr (q >= APW && q < APW + 8) {
                     dma_b(ob_n, sl_n, bbuf ^ 1u, q - APW);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (t8 < 7 && xi >= 6 && xi < 14) {
-                    if constexpr (xi < 10) {
-                        if constexpr (s == 0) transform_cols(std::integral_constant<int, 1>{}, xi - 6);
-                        else transform_cols(std::integral_constant<int, 0>{}, xi - 6);
-                    } else {
-                        transform_rows(v_n, xi - 10);
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
