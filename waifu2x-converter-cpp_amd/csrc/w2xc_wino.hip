@@ -149,13 +149,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     __builtin_amdgcn_s_barrier();
 
     unsigned abuf = 0, bbuf = 0;
-#ifdef W2XC_DBG_TIMING
-    unsigned long long T_st = 0, T_epi = 0, T0 = __builtin_amdgcn_s_memtime(); int n_it = 0;
-#endif
     for (;;) {
-#ifdef W2XC_DBG_TIMING
-      const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
       // The accumulators are DEFINED by the first stage of an item (its first 16 MFMAs take C = 0) and die in the epilogue: carried
       // across items they are 256 loop-carried registers whose phi copies the allocator routes through VGPRs and scratch.
       f32x16 acc[16];
@@ -271,10 +265,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
       stage(std::true_type{}, 0);
 #pragma unroll 1
       for (int sl = 1; sl < NSL; sl++) stage(std::false_type{}, sl);
-#ifdef W2XC_DBG_TIMING
-      const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-      T_st += t_b - t_a;
-#endif
         {
             // the hazard recogniser does not see inside inline asm: let the last MFMAs drain (16 passes) before VALU reads their results
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -321,309 +311,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
                                 *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 8 * q4) = y[i][j];
                 }
             }
-#ifdef W2XC_DBG_TIMING
-            T_epi += __builtin_amdgcn_s_memtime() - t_b; n_it++;
-#endif
             item += per;
             if (item >= chunk_end) break;
         }
     }
-#ifdef W2XC_DBG_TIMING
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
-        printf("TIMING wino %d->%d wave %d: items %d stages %llu epi %llu total %llu cycles\n", CIN, COUT, (int)(threadIdx.x >> 6), n_it, T_st, T_epi, __builtin_amdgcn_s_memtime() - T0);
-#endif
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv3x3_wino8: the same item on 8 waves, two per SIMD -- the partner's MFMAs cover this wave's LDS-DMA issue slots (130 cycles each,
-// 18 per 128 MFMAs: with one wave per SIMD they cost the stage loop a third of its time, ablation in profiles/r2_sweeps.log).  256
-// accumulator registers do not fit two waves per SIMD, so the 16 positions are SPLIT between a wave pair: wave (rg, hf) owns rows
-// 4rg .. 4rg+3 of the tile like before but only the positions xi = 8hf .. 8hf+7, i.e. rows i = 2hf, 2hf+1 of the transformed 4x4
-// (128 AGPRs + <= 128 VGPRs).  It needs 3 of the 4 patch rows (hf = 0: rows 0-2, t_0 = d0 - d2, t_1 = d1 + d2; hf = 1: rows 1-3,
-// t_2 = d2 - d1, t_3 = d1 - d3) and half the additions; the output transform Y = A^T M A mixes the halves, so the pair exchanges its
-// partial sums through LDS once per item: wave hf finishes output row hf of every 2x2 block.
-// ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int HF>
-static __device__ __forceinline__ void wino8_body(const W2xcConvDesc &d, int tiles_x, int nitems, float *lds)
-{
-    constexpr int ROWS = 16, HW = 34, HH = ROWS + 2, NPIX = HH * HW;
-    constexpr int NSL = CIN / 16, NOB = COUT / 32;
-    constexpr int NW = 8;
-    constexpr int A_SLOTS = NPIX * 4;
-    constexpr int APW = (A_SLOTS + NW * 64 - 1) / (NW * 64);   // 5 pieces per wave per slice
-    constexpr unsigned A_BYTES = NW * APW * 1024;          // 40 KiB
-    constexpr unsigned B_BYTES = 32 * 1024;
-    constexpr unsigned B_BASE = 2 * A_BYTES;
-    constexpr unsigned LOFS_BASE = B_BASE + 2 * B_BYTES;   // DMA offset table, 5 x 512 dwords
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
-    const char *ldsb = reinterpret_cast<const char *>(lds);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rg = wave >> 1;                               // row group: tile rows 4rg .. 4rg+3
-    const int n = lane & 31, kk = lane >> 5;
-    const int tyl = n >> 4, tx = n & 15;
-
-    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
-    const int cq = nitems >> 3, cr = nitems & 7;
-    const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-    const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
-    int item = chunk_begin + (blockIdx.x >> 3);
-    if (item >= chunk_end) return;
-
-    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(d.in);
-    unsigned goff[APW];
-    auto slot_of = [&](int jj, int &row, int &col, int &q) {
-        int s = (jj * NW + wave) * 64 + lane;
-        s = s < A_SLOTS ? s : A_SLOTS - 1;
-        const int pp = s >> 2;
-        q = (s & 3) ^ ((pp >> 2) & 3);
-        row = pp / HW;
-        const int rem = pp - row * HW;
-        col = rem < 17 ? 2 * rem : 2 * (rem - 17) + 1;
-    };
-    {
-        unsigned *lofs = reinterpret_cast<unsigned *>(const_cast<char *>(ldsb) + LOFS_BASE);
-#pragma unroll
-        for (int jj = 0; jj < APW; jj++) {
-            int row, col, q;
-            slot_of(jj, row, col, q);
-            lofs[jj * 512 + threadIdx.x] = (unsigned)(((long long)row * d.in_rs + (long long)col * CIN) >> 2) + q;
-        }
-    }
-    auto tile_offsets = [&](int it) {
-        const int pt = it / NOB;
-        const int ty_ = pt / tiles_x, tx_ = pt - ty_ * tiles_x;
-        const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
-        if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
-            const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * CIN) >> 2);
-            const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
-#pragma unroll
-            for (int jj = 0; jj < APW; jj++) goff[jj] = lofs[jj * 512 + threadIdx.x] + base;
-            return;
-        }
-#pragma unroll
-        for (int jj = 0; jj < APW; jj++) {
-            int row, col, q;
-            slot_of(jj, row, col, q);
-            const int gy = clampi(y0 + row, 0, d.in_h - 1);
-            const int gx = clampi(x0 + col, 0, d.in_w - 1);
-            goff[jj] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN) >> 2) + q;
-        }
-    };
-    auto dma_a = [&](unsigned add, unsigned abuf, int jj) {
-        lds_dma16(in4 + goff[jj] + add, lds0 + abuf * A_BYTES + (unsigned)(jj * NW + wave) * 1024u);
-    };
-    const unsigned b_voff = (unsigned)lane * 16u;
-    auto dma_b = [&](int ob, int sl_, unsigned buf, int jb) {   // piece wave*4 + jb of the 32
-        const char *sbase = reinterpret_cast<const char *>(d.wpk) + ((size_t)(ob * NSL + sl_) * 32 + wave * 4) * 1024;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + B_BASE + buf * B_BYTES + (unsigned)(wave * 4) * 1024u);
-        switch (jb) {
-        case 0: lds_dma16_s<0>(sbase, b_voff, dst); break;
-        case 1: lds_dma16_s<1024>(sbase, b_voff, dst); break;
-        case 2: lds_dma16_s<2048>(sbase, b_voff, dst); break;
-        default: lds_dma16_s<3072>(sbase, b_voff, dst); break;
-        }
-    };
-
-    // patch rows HF .. HF+2 of this lane's block (see conv3x3_wino for the layout of the tile in LDS).  The 12 fragment addresses are
-    // REcomputed from the block's first position at every patch read (~4 VALU each, every other step): kept in registers they are the
-    // first thing the allocator spills at 128 VGPRs, and a scratch reload waits for every transfer in flight (vmcnt is in order).
-    const unsigned pp0 = (unsigned)((4 * rg + 2 * tyl + HF) * HW + tx);
-    const unsigned kq = 2u * (unsigned)kk;
-    tile_offsets(item);
-#pragma unroll
-    for (int jj = 0; jj < APW; jj++) dma_a(0, 0, jj);
-#pragma unroll
-    for (int jb = 0; jb < 4; jb++) dma_b(item % NOB, 0, 0, jb);
-    W2XC_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-
-    unsigned abuf = 0, bbuf = 0;
-    for (;;) {
-      f32x16 acc[8];   // defined by the first stage of the item (C = 0), dead after the epilogue
-      auto stage = [&](auto FIRST, int sl) {
-        constexpr bool first = decltype(FIRST)::value;
-        const bool last_slice = (sl == NSL - 1);
-        const int item_n = item + per < chunk_end ? item + per : item;
-        unsigned a_add = (unsigned)(sl + 1) * 4;
-        int ob_n = item % NOB, sl_n = sl + 1;
-        if (last_slice) {
-            tile_offsets(item_n);
-            a_add = 0;
-            ob_n = item_n % NOB;
-            sl_n = 0;
-        }
-        f32x2v raw[12];
-        f32x4 u_c[2];
-        float v_c[8];
-        float tq[2][4];
-        auto load_raw = [&](int G) {
-            unsigned p0 = pp0;
-            asm volatile("" : "+v"(p0));   // (not loop-invariant for the optimiser: see above)
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const unsigned pp = p0 + (unsigned)(r * HW + (c >> 1) + 17 * (c & 1));
-                    const unsigned ad = (pp << 6) | ((((pp >> 2) & 3u) ^ kq ^ (unsigned)(G >> 1)) << 4);
-                    raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(ldsb + abuf * A_BYTES + ad + 8 * (G & 1));
-                }
-        };
-        auto load_u = [&](int q, int G, int s) {
-            u_c[q] = *reinterpret_cast<const f32x4 *>(ldsb + B_BASE + bbuf * B_BYTES + (((G * 2 + s) * 4 + 2 * HF + q) * 64 + lane) * 16);
-        };
-        // rows 2HF, 2HF+1 of B^T d:  HF = 0: d0 - d2, d1 + d2;  HF = 1 (patch rows 1..3 = raw rows 0..2): d2 - d1, d1 - d3
-        auto transform_cols = [&](auto S, int k) {
-            constexpr int s = decltype(S)::value;
-            const float r0 = raw[0 * 4 + k][s], r1 = raw[1 * 4 + k][s], r2 = raw[2 * 4 + k][s];
-            if constexpr (HF == 0) { tq[0][k] = r0 - r2; tq[1][k] = r1 + r2; }
-            else { tq[0][k] = r1 - r0; tq[1][k] = r0 - r2; }
-        };
-        auto transform_rows = [&](int k) {
-            v_c[k * 4 + 0] = tq[k][0] - tq[k][2];
-            v_c[k * 4 + 1] = tq[k][1] + tq[k][2];
-            v_c[k * 4 + 2] = tq[k][2] - tq[k][1];
-            v_c[k * 4 + 3] = tq[k][1] - tq[k][3];
-        };
-        load_raw(0);
-        load_u(0, 0, 0);
-        load_u(1, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 4; k++) transform_cols(std::integral_constant<int, 0>{}, k);
-        transform_rows(0);
-        transform_rows(1);
-        static_for<0, 8>([&](auto TT) {
-            constexpr int t8 = decltype(TT)::value, G = t8 >> 1, s = t8 & 1;
-            // 128 VGPRs: no second set of fragment registers.  A step's 8 MFMAs read u_c[0] / v_c[0..3] (MFMAs 0-3) and u_c[1] / v_c[4..7]
-            // (4-7); each half is refilled for the NEXT step as soon as its last reader has issued (MFMA operands are read at issue):
-            //   behind MFMA 2: one transfer of the next stage        behind MFMA 3: the column half of the next input transform (8 additions)
-            //   behind MFMA 4: u_c[0] and v_c[0..3] of the next step behind MFMA 5 (even steps): the patch of the next k-group (its
-            //   behind MFMA 7: u_c[1] and v_c[4..7]                                  registers are free: both channels are consumed)
-            static_for<0, 8>([&](auto XI) {
-                constexpr int xi = decltype(XI)::value;
-                if constexpr (first && t8 == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
-                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
-                __builtin_amdgcn_sched_barrier(0);
-                constexpr int q = xi == 2 ? t8 : (xi == 6 && t8 == 0) ? 8 : -1;   // the 5 + 4 transfers of the next stage
-                if constexpr (q >= 0 && q < APW) {
-                    dma_a(a_add, abuf ^ 1u, q);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else if constexpr (q >= APW && q < APW + 4) {
-                    dma_b(ob_n, sl_n, bbuf ^ 1u, q - APW);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (t8 < 7) {
-                    if constexpr (xi == 3) {
-                        static_for<0, 4>([&](auto K) {
-                            if constexpr (s == 0) transform_cols(std::integral_constant<int, 1>{}, decltype(K)::value);
-                            else transform_cols(std::integral_constant<int, 0>{}, decltype(K)::value);
-                        });
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi == 4) {
-                        load_u(0, (t8 + 1) >> 1, (t8 + 1) & 1);
-                        transform_rows(0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi == 5 && s == 0 && G < 3) {
-                        load_raw(G + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi == 7) {
-                        load_u(1, (t8 + 1) >> 1, (t8 + 1) & 1);
-                        transform_rows(1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            });
-        });
-        W2XC_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        abuf ^= 1u;
-        bbuf ^= 1u;
-      };
-      stage(std::true_type{}, 0);
-#pragma unroll 1
-      for (int sl = 1; sl < NSL; sl++) stage(std::false_type{}, sl);
-      {
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // (the hazard recogniser does not see inside the asm MFMAs)
-        // ---- epilogue.  Column transform of this wave's two rows of M, combined into its partial sums of the two OUTPUT rows:
-        //        HF = 0:  P0 = colT(M0 + M1), P1 = colT(M1)        HF = 1:  P0 = colT(M2), P1 = -colT(M2 + M3)
-        //      colT(m) = (m0 + m1 + m2, m1 - m2 - m3).  The wave keeps P_HF, sends P_(1-HF) to its partner through the LDS buffers the
-        //      last stage left free (A[abuf ^ 1]: waves 0..4, U[bbuf ^ 1]: waves 5..7; 8 KiB each), adds the partner's P_HF, and
-        //      stores output row HF of every 2x2 block: bias, LeakyReLU, 16-byte NHWC stores. ----
-        const int ob = item % NOB, pt = item / NOB;
-        const int tile_y = pt / tiles_x, tile_x = pt - tile_y * tiles_x;
-        const int oy = tile_y * ROWS - d.wino_py + 4 * rg + 2 * tyl + HF, ox = tile_x * 32 + 2 * tx;
-        float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * kk;
-        const int ty0 = tile_y * ROWS - d.wino_py;
-        const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
-        auto xbuf = [&](int w) -> unsigned {   // byte offset of wave w's exchange block
-            return w < 5 ? (abuf ^ 1u) * A_BYTES + (unsigned)w * 8192u : B_BASE + (bbuf ^ 1u) * B_BYTES + (unsigned)(w - 5) * 8192u;
-        };
-        float keep[16][2];
-        char *xw = const_cast<char *>(ldsb) + xbuf(wave) + lane * 16;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            f32x4 send[2];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int r = 4 * q4 + e;
-                float ma[4], mb[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { ma[j] = acc[j][r]; mb[j] = acc[4 + j][r]; }
-                float p0[4], p1[4];   // rows of M entering output row 0 / 1 from this wave
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if constexpr (HF == 0) { p0[j] = ma[j] + mb[j]; p1[j] = mb[j]; }
-                    else { p0[j] = ma[j]; p1[j] = -(ma[j] + mb[j]); }
-                }
-                const float c00 = p0[0] + p0[1] + p0[2], c01 = p0[1] - p0[2] - p0[3];
-                const float c10 = p1[0] + p1[1] + p1[2], c11 = p1[1] - p1[2] - p1[3];
-                if constexpr (HF == 0) { keep[r][0] = c00; keep[r][1] = c01; send[0][e] = c10; send[1][e] = c11; }
-                else { keep[r][0] = c10; keep[r][1] = c11; send[0][e] = c00; send[1][e] = c01; }
-            }
-            *reinterpret_cast<f32x4 *>(xw + (q4 * 2 + 0) * 1024) = send[0];
-            *reinterpret_cast<f32x4 *>(xw + (q4 * 2 + 1) * 1024) = send[1];
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char *xr = ldsb + xbuf(wave ^ 1) + lane * 16;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(xr + (q4 * 2 + 0) * 1024), g1 = *reinterpret_cast<const f32x4 *>(xr + (q4 * 2 + 1) * 1024);
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(d.bias + ob * 32 + 8 * q4 + 4 * kk);
-            f32x4 y[2];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float y0 = keep[4 * q4 + e][0] + g0[e] + bq[e], y1 = keep[4 * q4 + e][1] + g1[e] + bq[e];
-                y[0][e] = fmaxf(y0, 0.1f * y0);
-                y[1][e] = fmaxf(y1, 0.1f * y1);
-            }
-            if (interior) {
-#pragma unroll
-                for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4 *>(obase + j * COUT + 8 * q4) = y[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    if (oy >= 0 && oy < d.out_h && ox + j < d.out_w) *reinterpret_cast<f32x4 *>(obase + j * COUT + 8 * q4) = y[j];
-            }
-        }
-        __builtin_amdgcn_s_barrier();   // the exchange blocks are the next stage's DMA targets
-        asm volatile("" ::: "memory");
-        item += per;
-        if (item >= chunk_end) break;
-      }
-    }
-    W2XC_WAIT_VMCNT(0);
-}
-
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(512, 2) conv3x3_wino8(W2xcConvDesc d, int tiles_x, int nitems)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino8_body<CIN, COUT, 1>(d, tiles_x, nitems, lds);
-    else wino8_body<CIN, COUT, 0>(d, tiles_x, nitems, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -664,23 +356,19 @@ static hipError_t launch_wino(const W2xcConvDesc &d, hipStream_t stream)
     const int nitems = tiles_x * tiles_y * (COUT / 32);
     constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024) + 10 * 1024;   // tile + U ring + the DMA offset table
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    static int w8 = -1;
-    if (w8 < 0) { const char *e = getenv("W2XC_WINO_WAVES"); w8 = e ? (atoi(e) == 8) : 1; }   // (tuning aid: 4 = the one-wave-per-SIMD kernel)
-    auto kern = w8 ? conv3x3_wino8<CIN, COUT> : conv3x3_wino<CIN, COUT>;
-    const int nthreads = w8 ? 512 : 256;
+    auto kern = conv3x3_wino<CIN, COUT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino8<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         if (dev < 64) attr_done.fetch_or(1ull << dev);
     }
     int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((nitems + 7) & ~7)) grid = (nitems + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds_bytes, stream, d, tiles_x, nitems);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, d, tiles_x, nitems);
     return hipGetLastError();
 }
 
