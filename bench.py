@@ -27,10 +27,14 @@ HOST plane out (pad, H2D, layers, D2H, stitch; pageable numpy planes, median of 
 contract it is reported beside `value`, never as `value`.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = layer 6 (conv3x3_mfma2, 128->128, 51% of the FLOPs): algorithmic FLOPs of one
-               launch / its average duration from hipEvents recorded on the launch stream (w2xc_opts.profile) in a
-               second pass of the same K steps right after the timed region (so the events are not inside
+  roofline     dominant kernel = layer 6 (128->128, 51% of the FLOPs): ALGORITHMIC FLOPs of one launch (18*Cin*Cout per
+               pixel) / its average duration from hipEvents recorded on the launch stream (w2xc_opts.profile)
+               in a second pass of the same K steps right after the timed region (so the events are not inside
                `value`'s region; `ms_per_step_profiled` shows they cost nothing), vs the 157.3 TFLOP/s fp32 MFMA peak.
+               Since round 2 that layer runs conv3x3_wino (Winograd F(2x2,3x3): 16 instead of 36 multiplies per
+               plane pair and 2x2 block, all fp32), so `frac` on algorithmic FLOPs can exceed 1; `executed_frac`
+               is the fraction of the MFMA peak the kernel's own 16/36 of those FLOPs reach (W2XC_WINOGRAD=0 in the
+               environment runs conv3x3_mfma2, where the two coincide).
                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same command
                (profiles/r2_roofline.json), only when that profile was taken from the kernel sources being run
                (hash check), else null.
@@ -481,6 +485,11 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
                          "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops, "mfma_products_per_fma": products,
+                         "executed_flops_per_launch": dom_flops * products * (16.0 / 36.0 if "wino" in ms.kernel_name(dom, opts) else 1.0),
+                         "executed_frac": round(achieved / peak * (16.0 / 36.0 if "wino" in ms.kernel_name(dom, opts) else 1.0), 4),
+                         "note": ("conv3x3_wino: Winograd F(2x2,3x3) does 16/36 of the algorithmic multiplies, so `achieved` / `frac` (algorithmic FLOPs "
+                                  "over time, the contract's definition) exceed the MFMA roofline of a direct convolution; `executed_frac` is the MFMA "
+                                  "pipe's own utilisation" if "wino" in ms.kernel_name(dom, opts) else "direct convolution: executed = algorithmic FLOPs"),
                          "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,
             "output_finite": ok,

@@ -6,6 +6,9 @@ import ctypes as C
 import os
 import re
 
+# fp32 kernel of the 64- / 128-plane layers: Winograd unless W2XC_WINOGRAD=0 is in the environment (read once per process)
+MID_128 = "conv3x3_mfma" if os.environ.get("W2XC_WINOGRAD", "1") == "0" else "conv3x3_wino"
+
 import numpy as np
 import pytest
 
@@ -140,7 +143,7 @@ def test_opts_struct_size_versions_the_abi(w2xc, noise1_layers):
     assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == b"conv3x3_direct"
     old.kernel = w2xc.KERNEL_AUTO
     C.memmove(buf, C.byref(old), C.sizeof(old))
-    assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == b"conv3x3_mfma"
+    assert name(ms.handle, 5, C.cast(buf, C.POINTER(w2xc.Opts))) == MID_128.encode()
     # precision travels in the prefix too: a 16-bit mode picks the split kernels
     old.precision = w2xc.PRECISION_FP16X2
     C.memmove(buf, C.byref(old), C.sizeof(old))
@@ -185,7 +188,8 @@ def test_argument_validation(w2xc, noise1_layers):
     with pytest.raises(w2xc.W2xcError) as e:
         ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
     assert e.value.code == w2xc.ERR_PLANES
-    assert ms.kernel_name(5) == "conv3x3_mfma" and ms.kernel_name(0) == "conv3x3_first" and ms.kernel_name(6) == "conv3x3_last"
+    assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first" and ms.kernel_name(6) == "conv3x3_last"
+    assert ms.kernel_name(1) == "conv3x3_mfma"            # 32 -> 32: no Winograd shape, the direct fp32 MFMA kernel
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
 
 

@@ -41,6 +41,9 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         if k == NL and any(n.startswith("conv3x3_last_gather") for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
+    if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino<CIN, COUT>)
+        sub = "conv3x3_wino<%d, %d>" % (cin, cout)
+        names = [n for n in stats if sub in n]
     if not names:
         continue
     name = names[0]
@@ -58,7 +61,8 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         alg = (4 + cout * out_bpe) * px                 # reads the input plane, layer 1's activations never reach HBM
     if T > 0 and k == NL - 1 and any(n.startswith("conv3x3_last_gather") for n in stats):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
-    e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px,
+    wino = "conv3x3_wino" in name
+    e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": 16.0 / 36.0 if wino else 1.0,
          "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,
          "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
