@@ -1,0 +1,73 @@
+"""conv3x3_wino (Winograd F(2x2,3x3) on the fp32 MFMA, csrc/w2xc_wino.hip) against the direct fp32 MFMA kernel it replaces on the
+64 / 128-plane layers and against the CPU oracle of Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159).
+W2XC_WINOGRAD is read once per process, so the two kernels run in two subprocesses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(w2xc):
+    assert w2xc.device_count() >= 1, "no HIP device visible: libw2xc_hip has no CPU fallback, -m gpu tests need an MI355X"
+    return w2xc
+
+CODE = (
+    "import sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import __graft_entry__ as g; from tools import gen_model\n"
+    "w = g.load_package(); outs = []; names = []\n"
+    # every shape conv3x3_wino instantiates (64->64, 64->128, 128->64, 128->128), behind 32-plane layers that stay on conv3x3_mfma2
+    "for planes, seed in (([1, 32, 64, 64, 128, 128, 1], 31), ([1, 64, 128, 64, 64, 1], 32), ([1, 32, 64, 128, 128, 64, 1], 33)):\n"
+    "    layers = gen_model.synth_layers(planes, seed)\n"
+    "    ms = w._ModelSet.from_layers(layers)\n"
+    "    names += [ms.kernel_name(l) for l in range(len(planes) - 1)]\n"
+    "    for (h, wd) in ((37, 61), (8, 32), (130, 70), (16, 33)):\n"
+    "        x = np.random.default_rng(h * 7 + wd).random((h, wd), dtype=np.float32)\n"
+    "        a = ms.convert(x)\n"
+    "        outs.append(a.ravel())\n"
+    "        for band in (1, 5, 16):\n"                       # odd and even band origins: the 2x2 blocks stay on even rows of the plane
+    "            assert np.array_equal(a, ms.convert(x, opts=w.make_opts(band_rows=band))), ('banding', planes, h, wd, band)\n"
+    "        outs.append(ms.convert_nn2x(x).ravel())\n"
+    "    l = next(i for i in range(len(planes) - 1) if planes[i] >= 64 and planes[i + 1] >= 64)\n"
+    "    outs.append(ms.filter(l, np.random.default_rng(6).random((planes[l], 21, 45), dtype=np.float32)).ravel())\n"   # Model::filter: same-size conv
+    "np.save(sys.argv[1], np.concatenate(outs)); open(sys.argv[1] + '.names', 'w').write(','.join(names))\n" % ROOT)
+
+
+def _run(tmp_path, flag):
+    f = str(tmp_path / ("w%s.npy" % flag))
+    r = subprocess.run([sys.executable, "-c", CODE, f], env=dict(os.environ, W2XC_WINOGRAD=flag), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(f), open(f + ".names").read().split(",")
+
+
+def test_winograd_vs_direct_mfma(gpu, tmp_path):
+    """same fp32 arithmetic type, other summation order: every output within 4e-6 of the output range of the direct MFMA kernel's
+    (two fp32 summation orders differ by about that much: conv3x3_mfma2 vs the oracle is 3-4e-6 too); odd sizes, tiles smaller than a
+    work item, banding from odd and even rows (bit-identical inside the Winograd run), nearest-2x entry, Model::filter."""
+    a, names_w = _run(tmp_path, "1")
+    b, names_d = _run(tmp_path, "0")
+    assert "conv3x3_wino" in names_w and "conv3x3_wino" not in names_d and names_d.count("conv3x3_mfma") == names_w.count("conv3x3_mfma") + names_w.count("conv3x3_wino")
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 4e-6 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("planes", [[1, 64, 64, 1], [1, 32, 128, 128, 1], [1, 64, 128, 64, 1]])
+def test_winograd_vs_oracle(gpu, planes):
+    """against the CPU oracle, rtol 1e-4 + atol 1e-5 (north_star) and max-norm 1e-5, on a plane that is not a multiple of the 16 x 32 work item"""
+    from oracle import oracle as orc
+    from tools import gen_model
+    if os.environ.get("W2XC_WINOGRAD", "1") == "0":
+        pytest.skip("Winograd disabled in this environment")
+    layers = gen_model.synth_layers(planes, 900 + len(planes))
+    ms = gpu._ModelSet.from_layers(layers)
+    assert "conv3x3_wino" in [ms.kernel_name(l) for l in range(len(planes) - 1)]
+    x = np.random.default_rng(11).random((75, 101), dtype=np.float32)
+    got, want = ms.convert(x), orc.Oracle(layers).convert(x)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
