@@ -321,7 +321,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-bool w2xc_wino_supported(int cin, int cout) { return (cin == 64 || cin == 128) && (cout == 64 || cout == 128); }
+// W2XC_WINO_MIN_CIN (tuning aid, default 64): smallest input plane count that takes this kernel
+bool w2xc_wino_supported(int cin, int cout)
+{
+    static int min_cin = -1;
+    if (min_cin < 0) { const char *e = getenv("W2XC_WINO_MIN_CIN"); min_cin = e ? atoi(e) : 64; }
+    return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128) && cin >= min_cin && cout >= min_cin;
+}
 
 size_t w2xc_wino_packed_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
@@ -379,6 +385,11 @@ hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream)
     if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1 || d.in_shift != 0) return hipErrorInvalidValue;
     if ((d.in_rs & 3) != 0 || (d.out_rs & 3) != 0) return hipErrorInvalidValue;   // 16-byte accesses
     switch (d.cin * 1000 + d.cout) {
+    case 32032:  return launch_wino<32, 32>(d, stream);
+    case 32064:  return launch_wino<32, 64>(d, stream);
+    case 32128:  return launch_wino<32, 128>(d, stream);
+    case 64032:  return launch_wino<64, 32>(d, stream);
+    case 128032: return launch_wino<128, 32>(d, stream);
     case 64064:  return launch_wino<64, 64>(d, stream);
     case 64128:  return launch_wino<64, 128>(d, stream);
     case 128064: return launch_wino<128, 64>(d, stream);
