@@ -81,6 +81,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     // tile-independent part of the offsets (interior tiles: + one base): per-lane constants, parked in LDS (10 KiB behind the U ring)
     // rather than in 10 registers -- the stage needs every VGPR, and the clamped path costs ~10k cycles per item when taken each time
     constexpr unsigned LOFS_BASE = B_BASE + 2 * B_BYTES;
+    constexpr unsigned BIAS_BASE = LOFS_BASE + APW * 256 * 4;   // bias[COUT]: read in every item's epilogue (a global load there is an exposed round trip)
+    for (int c = threadIdx.x; c < COUT; c += 256) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
     {
         unsigned *lofs = reinterpret_cast<unsigned *>(const_cast<char *>(ldsb) + LOFS_BASE);
 #pragma unroll
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(d.bias + ob * 32 + 8 * q4 + 4 * kk);
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + (ob * 32 + 8 * q4 + 4 * kk) * 4);
                 f32x4 y[2][2];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -360,7 +362,7 @@ static hipError_t launch_wino(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 1) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 32);
-    constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024) + 10 * 1024;   // tile + U ring + the DMA offset table
+    constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024) + 10 * 1024 + COUT * 4;   // tile + U ring + the DMA offset table + bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_wino<CIN, COUT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
