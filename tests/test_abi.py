@@ -189,7 +189,7 @@ def test_argument_validation(w2xc, noise1_layers):
         ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
     assert e.value.code == w2xc.ERR_PLANES
     assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first" and ms.kernel_name(6) == "conv3x3_last"
-    assert ms.kernel_name(1) == "conv3x3_mfma"            # 32 -> 32: no Winograd shape, the direct fp32 MFMA kernel
+    assert ms.kernel_name(1) == MID_128                   # 32 -> 32 too (W2XC_WINO_MIN_CIN=64 would keep the direct kernel there)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
 
 

@@ -22,7 +22,7 @@ CODE = (
     "import sys, numpy as np; sys.path.insert(0, %r)\n"
     "import __graft_entry__ as g; from tools import gen_model\n"
     "w = g.load_package(); outs = []; names = []\n"
-    # every shape conv3x3_wino instantiates (64->64, 64->128, 128->64, 128->128), behind 32-plane layers that stay on conv3x3_mfma2
+    # shapes conv3x3_wino instantiates: 32->64, 64->64, 64->128, 128->128, 128->64, 32->64->128 ...
     "for planes, seed in (([1, 32, 64, 64, 128, 128, 1], 31), ([1, 64, 128, 64, 64, 1], 32), ([1, 32, 64, 128, 128, 64, 1], 33)):\n"
     "    layers = gen_model.synth_layers(planes, seed)\n"
     "    ms = w._ModelSet.from_layers(layers)\n"
@@ -53,6 +53,7 @@ def test_winograd_vs_direct_mfma(gpu, tmp_path):
     a, names_w = _run(tmp_path, "1")
     b, names_d = _run(tmp_path, "0")
     assert "conv3x3_wino" in names_w and "conv3x3_wino" not in names_d and names_d.count("conv3x3_mfma") == names_w.count("conv3x3_mfma") + names_w.count("conv3x3_wino")
+    assert names_w.count("conv3x3_wino") == names_d.count("conv3x3_mfma")   # every mid layer (32 / 64 / 128 planes in and out) takes the Winograd kernel
     assert a.shape == b.shape and np.isfinite(a).all()
     assert np.abs(a - b).max() <= 4e-6 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
 

@@ -25,7 +25,12 @@
 //              bits 2..3 of the pixel index, so the 32 lanes that read patch element (r, c) of horizontally adjacent
 //              blocks (2 pixels apart) spread over the banks.
 //              B[2] x 32 KiB: U of one (plane block, slice) in fragment order [k-group][step][xi/4][lane][xi%4].
+//              + 10 KiB: the per-lane source offsets of the 10 tile pieces a wave transfers per slice (registers are the scarce
+//              resource: 256 accumulators + ~200 VGPRs), + the bias vector.
 //   Epilogue   output transform (24 additions per plane), bias, LeakyReLU, 16-byte NHWC stores.
+//   Banding    the 2x2 blocks sit on EVEN rows of the layer's whole output (W2xcConvDesc::wino_py): results do not depend on the band origin.
+// Measured (round 2, 2160x3840, profiles/): 128->128 10.4 ms vs 16.9 ms for conv3x3_mfma2 -- 235 TFLOP/s of algorithmic FLOPs, 1.5x the
+// MFMA roofline of a direct convolution, 2/3 of the MFMA peak on the multiplies it really issues; what the rest is, DESIGN.md 3.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
@@ -323,11 +328,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// W2XC_WINO_MIN_CIN (tuning aid, default 64): smallest input plane count that takes this kernel
+// W2XC_WINO_MIN_CIN (tuning aid, default 32 = every mid shape): smallest plane count that takes this kernel
 bool w2xc_wino_supported(int cin, int cout)
 {
     static int min_cin = -1;
-    if (min_cin < 0) { const char *e = getenv("W2XC_WINO_MIN_CIN"); min_cin = e ? atoi(e) : 64; }
+    if (min_cin < 0) { const char *e = getenv("W2XC_WINO_MIN_CIN"); min_cin = e ? atoi(e) : 32; }
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128) && cin >= min_cin && cout >= min_cin;
 }
 
