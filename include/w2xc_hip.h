@@ -36,9 +36,9 @@ extern "C" {
  * (one w2xc::Model per conv layer, modelHandler.hpp:24-90). */
 typedef struct w2xc_model w2xc_model;
 
-#define W2XC_PRECISION_FP32 0   /* fp32 throughout on v_mfma_f32_32x32x2_f32: Winograd F(2x2,3x3) for the 64 / 128-plane
-                                 * layers (conv3x3_wino; W2XC_WINOGRAD=0 in the environment disables it), exact-f32 fma
-                                 * chains (conv3x3_mfma2) for the rest; rtol 1e-4 vs the reference either way */
+#define W2XC_PRECISION_FP32 0   /* fp32 throughout on v_mfma_f32_32x32x2_f32: Winograd F(2x2,3x3) for the layers with 32 / 64 /
+                                 * 128 planes in and out (conv3x3_wino; W2XC_WINOGRAD=0 in the environment selects the
+                                 * exact-f32 fma chains of conv3x3_mfma2 instead); rtol 1e-4 vs the reference either way */
 #define W2XC_PRECISION_BF16 1   /* w2xc_convert_* only: activations BETWEEN layers are bf16 (RNE), layers
                                  * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
                                  * accumulate, bias and LeakyReLU; the first layer stays fp32, a one-plane
