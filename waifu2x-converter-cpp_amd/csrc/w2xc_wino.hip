@@ -176,7 +176,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
         // ---- one stage: 4 k-groups x 2 steps x 16 MFMAs ----
         f32x2v raw[16];
         f32x4 u_c[4], u_n[4];
-        float v_c[16], v_n[16];
+        // V = B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]) for BOTH channels of a k-group at once, on the 2-vectors the
+        // patch reads deliver (v_pk_add_f32: 32 per k-group): v2[kg & 1][xi][s] is the B operand of MFMA xi of step (kg, s).
+        f32x2v v2[2][16];
+        f32x2v tq2[4][4];
         auto load_raw = [&](int G) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
@@ -189,28 +192,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             for (int q = 0; q < 4; q++)
                 u[q] = *reinterpret_cast<const f32x4 *>(ldsb + B_BASE + bbuf * B_BYTES + (((G * 2 + s) * 4 + q) * 64 + lane) * 16);
         };
-        // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: columns of d first (tq), then rows
-        float tq[4][4];
-        auto transform_cols = [&](auto S, int k) {
-            constexpr int s = decltype(S)::value;
-            const float d0 = raw[0 * 4 + k][s], d1 = raw[1 * 4 + k][s], d2 = raw[2 * 4 + k][s], d3 = raw[3 * 4 + k][s];
-            tq[0][k] = d0 - d2;
-            tq[1][k] = d1 + d2;
-            tq[2][k] = d2 - d1;
-            tq[3][k] = d1 - d3;
+        auto transform_cols = [&](int k) {   // columns of d first (tq2), then rows
+            const f32x2v d0 = raw[0 * 4 + k], d1 = raw[1 * 4 + k], d2 = raw[2 * 4 + k], d3 = raw[3 * 4 + k];
+            tq2[0][k] = d0 - d2;
+            tq2[1][k] = d1 + d2;
+            tq2[2][k] = d2 - d1;
+            tq2[3][k] = d1 - d3;
         };
-        auto transform_rows = [&](float (&v)[16], int k) {
-            v[k * 4 + 0] = tq[k][0] - tq[k][2];
-            v[k * 4 + 1] = tq[k][1] + tq[k][2];
-            v[k * 4 + 2] = tq[k][2] - tq[k][1];
-            v[k * 4 + 3] = tq[k][1] - tq[k][3];
+        auto transform_rows = [&](f32x2v (&v)[16], int k) {
+            v[k * 4 + 0] = tq2[k][0] - tq2[k][2];
+            v[k * 4 + 1] = tq2[k][1] + tq2[k][2];
+            v[k * 4 + 2] = tq2[k][2] - tq2[k][1];
+            v[k * 4 + 3] = tq2[k][1] - tq2[k][3];
         };
         load_raw(0);
         load_u(u_c, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) transform_cols(std::integral_constant<int, 0>{}, k);
+        for (int k = 0; k < 4; k++) transform_cols(k);
 #pragma unroll
-        for (int k = 0; k < 4; k++) transform_rows(v_c, k);
+        for (int k = 0; k < 4; k++) transform_rows(v2[0], k);
         auto load_raw1 = [&](int G, int r, int c) {
             raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(ldsb + abuf * A_BYTES + (a1[r][c] ^ (unsigned)((G >> 1) << 4)) + 8 * (G & 1));
         };
@@ -221,29 +221,29 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             constexpr int t8 = decltype(TT)::value, G = t8 >> 1, s = t8 & 1;
             // Every non-MFMA instruction is pinned into the shadow of one of the step's 16 MFMAs, a FEW per MFMA (a wave issues in order:
             // the 20 fragment reads of a step behind ONE MFMA held the next MFMA back 350-500 cycles, s_memtime per step):
-            //   behind MFMAs 0..7  (odd steps) the patch of the next k-group, two b64 reads each, column by column
-            //   behind MFMAs 8..11 one b128 of the next step's U and one column of its input transform (4 additions)
-            //   behind MFMAs 12..15 one row of the input transform (4 additions)
+            //   behind MFMAs 0..7   (even steps) the patch of the next k-group, two b64 reads each, column by column (the patch registers are
+            //                       free: the previous odd step transformed both channels of the current k-group)
+            //   behind MFMAs 8..11  one b128 of the next step's U; (odd steps) one column of the next k-group's input transform, 4 packed additions
+            //   behind MFMAs 12..15 (odd steps) one row of it, 4 packed additions
             //   behind MFMAs 1, 6, 11 one transfer of the next stage (10 tile pieces + 8 U pieces over the 8 steps)
             static_for<0, 16>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                if constexpr (first && t8 == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
-                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v_c[xi]));
+                if constexpr (first && t8 == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v2[G & 1][xi][s]));
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[xi]) : "v"(u_c[xi >> 2][xi & 3]), "v"(v2[G & 1][xi][s]));
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (t8 < 7) {
-                    if constexpr (xi < 8 && s == 1) {   // (the patch registers are free: the even step consumed the second channel)
+                    if constexpr (xi < 8 && s == 0 && G < 3) {
                         load_raw1(G + 1, (2 * xi) & 3, xi >> 1);
                         load_raw1(G + 1, (2 * xi + 1) & 3, xi >> 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (xi >= 8 && xi < 12) {
                         load_u1(xi - 8, (t8 + 1) >> 1, (t8 + 1) & 1);
-                        if constexpr (s == 0) transform_cols(std::integral_constant<int, 1>{}, xi - 8);
-                        else transform_cols(std::integral_constant<int, 0>{}, xi - 8);
+                        if constexpr (s == 1) transform_cols(xi - 8);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (xi >= 12) {
-                        transform_rows(v_n, xi - 12);
+                    if constexpr (xi >= 12 && s == 1) {
+                        transform_rows(v2[(G + 1) & 1], xi - 12);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -257,8 +257,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
                 }
             });
             if constexpr (t8 < 7) {
-#pragma unroll
-                for (int xi = 0; xi < 16; xi++) v_c[xi] = v_n[xi];
 #pragma unroll
                 for (int q = 0; q < 4; q++) u_c[q] = u_n[q];
             }
