@@ -450,6 +450,9 @@ def main():
                               "ms": round(ms_l, 4),
                               "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None,
                               "frac_of_peak": round(products * flops_layer[l] / (ms_l * 1e-3) / 1e12 / peak, 4) if ms_l > 0 else None,
+                              # (algorithmic FLOPs; conv3x3_wino issues 16/36 of them, so its MFMA-pipe share is:)
+                              "executed_frac_of_peak": round(products * flops_layer[l] / (ms_l * 1e-3) / 1e12 / peak *
+                                                             (16.0 / 36.0 if "wino" in ms.kernel_name(l, opts) else 1.0), 4) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
         traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
                                  if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else (None, "no PMC profile for this configuration"))
