@@ -56,8 +56,14 @@ typedef struct w2xc_model w2xc_model;
                                  * layers 1..n-2 saturate at +-65504 and carry 2^-25 ABSOLUTE precision below
                                  * 2^-3 -- meant for image planes in [0, 1].                   */
 
-#define W2XC_KERNEL_AUTO    0   /* MFMA implicit-GEMM where the layer shape allows                 */
-#define W2XC_KERNEL_DIRECT  1   /* reference-ordered direct conv on VALU (bit-exact vs the oracle) */
+#define W2XC_KERNEL_AUTO    0   /* the fast kernel of each layer shape; for the fp32 layers with 32 / 64 / 128 planes in and out that
+                                 * is the process default: Winograd (conv3x3_wino16) unless the environment says W2XC_WINOGRAD=0
+                                 * (then W2XC_KERNEL_MFMA) or W2XC_WINO_KERNEL=32 (then W2XC_KERNEL_WINOGRAD32)            */
+#define W2XC_KERNEL_DIRECT  1   /* every layer: reference-ordered direct conv on VALU (bit-exact vs the oracle)             */
+#define W2XC_KERNEL_MFMA    2   /* mid layers: direct implicit GEMM, a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32
+                                 * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
+#define W2XC_KERNEL_WINOGRAD 3  /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (conv3x3_wino16), fp32 throughout */
+#define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: the round-2 Winograd kernel on v_mfma_f32_32x32x2_f32 (conv3x3_wino)        */
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */

@@ -1,14 +1,9 @@
-"""conv3x3_wino (Winograd F(2x2,3x3) on the fp32 MFMA, csrc/w2xc_wino.hip) against the direct fp32 MFMA kernel it replaces on the
-64 / 128-plane layers and against the CPU oracle of Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159).
-W2XC_WINOGRAD is read once per process, so the two kernels run in two subprocesses."""
-import os
-import subprocess
-import sys
-
+"""The Winograd F(2x2,3x3) kernels of the fp32 mid layers -- conv3x3_wino16 (csrc/w2xc_wino16.hip, v_mfma_f32_16x16x4_f32, the default)
+and conv3x3_wino (csrc/w2xc_wino.hip, v_mfma_f32_32x32x2_f32, round 2) -- against the direct fp32 MFMA kernel (conv3x3_mfma2) and the
+CPU oracle of Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159).  The kernel is chosen per call through
+w2xc_opts.kernel (W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32), so all three run in this one process."""
 import numpy as np
 import pytest
-
-from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -18,57 +13,76 @@ def gpu(w2xc):
     assert w2xc.device_count() >= 1, "no HIP device visible: libw2xc_hip has no CPU fallback, -m gpu tests need an MI355X"
     return w2xc
 
-CODE = (
-    "import sys, numpy as np; sys.path.insert(0, %r)\n"
-    "import __graft_entry__ as g; from tools import gen_model\n"
-    "w = g.load_package(); outs = []; names = []\n"
-    # shapes conv3x3_wino instantiates: 32->64, 64->64, 64->128, 128->128, 128->64, 32->64->128 ...
-    "for planes, seed in (([1, 32, 64, 64, 128, 128, 1], 31), ([1, 64, 128, 64, 64, 1], 32), ([1, 32, 64, 128, 128, 64, 1], 33)):\n"
-    "    layers = gen_model.synth_layers(planes, seed)\n"
-    "    ms = w._ModelSet.from_layers(layers)\n"
-    "    names += [ms.kernel_name(l) for l in range(len(planes) - 1)]\n"
-    "    for (h, wd) in ((37, 61), (8, 32), (130, 70), (16, 33)):\n"
-    "        x = np.random.default_rng(h * 7 + wd).random((h, wd), dtype=np.float32)\n"
-    "        a = ms.convert(x)\n"
-    "        outs.append(a.ravel())\n"
-    "        for band in (1, 5, 16):\n"                       # odd and even band origins: the 2x2 blocks stay on even rows of the plane
-    "            assert np.array_equal(a, ms.convert(x, opts=w.make_opts(band_rows=band))), ('banding', planes, h, wd, band)\n"
-    "        outs.append(ms.convert_nn2x(x).ravel())\n"
-    "    l = next(i for i in range(len(planes) - 1) if planes[i] >= 64 and planes[i + 1] >= 64)\n"
-    "    outs.append(ms.filter(l, np.random.default_rng(6).random((planes[l], 21, 45), dtype=np.float32)).ravel())\n"   # Model::filter: same-size conv
-    "np.save(sys.argv[1], np.concatenate(outs)); open(sys.argv[1] + '.names', 'w').write(','.join(names))\n" % ROOT)
+
+KERNELS = {"conv3x3_wino16": "KERNEL_WINOGRAD", "conv3x3_wino": "KERNEL_WINOGRAD32", "conv3x3_mfma": "KERNEL_MFMA"}
 
 
-def _run(tmp_path, flag):
-    f = str(tmp_path / ("w%s.npy" % flag))
-    r = subprocess.run([sys.executable, "-c", CODE, f], env=dict(os.environ, W2XC_WINOGRAD=flag), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return np.load(f), open(f + ".names").read().split(",")
+def _opts(w, name, **kw):
+    return w.make_opts(kernel=getattr(w, KERNELS[name]), **kw)
 
 
-def test_winograd_vs_direct_mfma(gpu, tmp_path):
+def _run(w, name):
+    """every instantiated shape (32/64/128 -> 32/64/128), odd sizes, planes smaller than a work item, banding, nearest-2x, Model::filter"""
+    from tools import gen_model
+    outs, names = [], []
+    for planes, seed in (([1, 32, 64, 64, 128, 128, 1], 31), ([1, 64, 128, 64, 64, 1], 32), ([1, 32, 64, 128, 128, 64, 1], 33),
+                         ([1, 32, 32, 128, 32, 1], 34), ([1, 64, 32, 1], 35)):
+        layers = gen_model.synth_layers(planes, seed)
+        ms = w._ModelSet.from_layers(layers)
+        names += [ms.kernel_name(l, _opts(w, name)) for l in range(len(planes) - 1)]
+        for (h, wd) in ((37, 61), (8, 32), (130, 70), (16, 33), (1, 1)):
+            x = np.random.default_rng(h * 7 + wd).random((h, wd), dtype=np.float32)
+            a = ms.convert(x, opts=_opts(w, name))
+            outs.append(a.ravel())
+            for band in (1, 5, 16):   # odd and even band origins: the 2x2 blocks stay on even rows of the plane
+                assert np.array_equal(a, ms.convert(x, opts=_opts(w, name, band_rows=band))), ("banding", name, planes, h, wd, band)
+            outs.append(ms.convert_nn2x(x, opts=_opts(w, name)).ravel())
+        l = next(i for i in range(len(planes) - 1) if planes[i] >= 32 and planes[i + 1] >= 32)
+        outs.append(ms.filter(l, np.random.default_rng(6).random((planes[l], 21, 45), dtype=np.float32), opts=_opts(w, name)).ravel())   # same-size conv
+    return np.concatenate(outs), names
+
+
+@pytest.fixture(scope="module")
+def runs(gpu):
+    return {name: _run(gpu, name) for name in KERNELS}
+
+
+@pytest.mark.parametrize("name", ["conv3x3_wino16", "conv3x3_wino"])
+def test_winograd_vs_direct_mfma(gpu, runs, name):
     """same fp32 arithmetic type, other summation order: every output within 4e-6 of the output range of the direct MFMA kernel's
-    (two fp32 summation orders differ by about that much: conv3x3_mfma2 vs the oracle is 3-4e-6 too); odd sizes, tiles smaller than a
-    work item, banding from odd and even rows (bit-identical inside the Winograd run), nearest-2x entry, Model::filter."""
-    a, names_w = _run(tmp_path, "1")
-    b, names_d = _run(tmp_path, "0")
-    assert "conv3x3_wino" in names_w and "conv3x3_wino" not in names_d and names_d.count("conv3x3_mfma") == names_w.count("conv3x3_mfma") + names_w.count("conv3x3_wino")
-    assert names_w.count("conv3x3_wino") == names_d.count("conv3x3_mfma")   # every mid layer (32 / 64 / 128 planes in and out) takes the Winograd kernel
+    (two fp32 summation orders differ by about that much: conv3x3_mfma2 vs the oracle is 3-4e-6 too); banding from odd and even rows
+    is bit-identical inside each kernel's run."""
+    a, names_w = runs[name]
+    b, names_d = runs["conv3x3_mfma"]
+    assert name in names_w and name not in names_d
+    assert names_w.count(name) == names_d.count("conv3x3_mfma")   # every mid layer (32 / 64 / 128 planes in and out) takes the Winograd kernel
     assert a.shape == b.shape and np.isfinite(a).all()
-    assert np.abs(a - b).max() <= 4e-6 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+    err = np.abs(a - b).max() / np.abs(b).max()
+    print("%s vs conv3x3_mfma2: max err %.2e of the output range" % (name, err))
+    assert err <= 4e-6, err
 
 
-@pytest.mark.parametrize("planes", [[1, 64, 64, 1], [1, 32, 128, 128, 1], [1, 64, 128, 64, 1]])
-def test_winograd_vs_oracle(gpu, planes):
-    """against the CPU oracle, rtol 1e-4 + atol 1e-5 (north_star) and max-norm 1e-5, on a plane that is not a multiple of the 16 x 32 work item"""
+def test_kernel_choice_per_call(gpu):
+    import os
+    from tools import gen_model
+    ms = gpu._ModelSet.from_layers(gen_model.synth_layers([1, 32, 64, 1], 5))
+    if os.environ.get("W2XC_WINOGRAD", "1") != "0":
+        assert ms.kernel_name(1) == ms.kernel_name(1, gpu.make_opts()) and ms.kernel_name(1).startswith("conv3x3_wino")
+    assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_MFMA)) == "conv3x3_mfma"
+    assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD32)) == "conv3x3_wino"
+    assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_DIRECT)) == "conv3x3_direct"
+
+
+@pytest.mark.parametrize("name", ["conv3x3_wino16", "conv3x3_wino"])
+@pytest.mark.parametrize("planes", [[1, 64, 64, 1], [1, 32, 128, 128, 1], [1, 64, 128, 64, 1], [1, 32, 32, 32, 1]])
+def test_winograd_vs_oracle(gpu, planes, name):
+    """against the CPU oracle, rtol 1e-4 + atol 1e-5 (north_star) and max-norm 1e-5, on a plane that is not a multiple of the work item"""
     from oracle import oracle as orc
     from tools import gen_model
-    if os.environ.get("W2XC_WINOGRAD", "1") == "0":
-        pytest.skip("Winograd disabled in this environment")
     layers = gen_model.synth_layers(planes, 900 + len(planes))
     ms = gpu._ModelSet.from_layers(layers)
-    assert "conv3x3_wino" in [ms.kernel_name(l) for l in range(len(planes) - 1)]
+    assert name in [ms.kernel_name(l, _opts(gpu, name)) for l in range(len(planes) - 1)]
     x = np.random.default_rng(11).random((75, 101), dtype=np.float32)
-    got, want = ms.convert(x), orc.Oracle(layers).convert(x)
+    got, want = ms.convert(x, opts=_opts(gpu, name)), orc.Oracle(layers).convert(x)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()

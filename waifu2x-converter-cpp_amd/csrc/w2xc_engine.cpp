@@ -78,7 +78,8 @@ struct DevLayer {
     W2xcKernelKind fast = W2XC_K_DIRECT;
     float *w_fast = nullptr;
     float *w_direct = nullptr;
-    float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path), packed on first use
+    float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path, 32x32x2 kernel), packed on first use
+    float *w_wino16 = nullptr;   // w2xc_wino16_pack image (fp32 Winograd path, 16x16x4 kernel), packed on first use
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
@@ -172,6 +173,7 @@ struct DevCtx {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_wino) hipFree(l.w_wino);
+            if (l.w_wino16) hipFree(l.w_wino16);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
             for (float *p : l.w_last_fused)
@@ -389,17 +391,35 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
     return W2XC_OK;
 }
 
-// fp32 path: Winograd F(2x2,3x3) (conv3x3_wino) for the shapes it covers -- 64 / 128 planes in and out -- unless W2XC_WINOGRAD=0,
-// which keeps conv3x3_mfma2 everywhere.  Same arithmetic type (fp32 throughout), 2.25x fewer multiplies, another summation order:
-// held to the same rtol 1e-4 gate against the CPU oracle by the same tests.
-bool wino_enabled()
+// fp32 path, layers with 32 / 64 / 128 planes in and out (W2XC_K_MFMA): which kernel runs them.
+//   MID_MFMA    conv3x3_mfma2: direct implicit GEMM, a k-ordered fp32 fma chain (the closest MFMA analogue of modelHandler.cpp:134-145)
+//   MID_WINO32  conv3x3_wino:   Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, one wave per SIMD (round 2)
+//   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two workgroups per CU (round 3)
+// Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
+// rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
+// _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel if W2XC_WINO_KERNEL=16.
+enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2 };
+int mid_variant(const w2xc_opts &o)
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("W2XC_WINOGRAD"); v = e ? (atoi(e) != 0) : 1; }
-    return v != 0;
+    static const int env_default = [] {
+        const char *e = getenv("W2XC_WINOGRAD");
+        if (e && atoi(e) == 0) return (int)MID_MFMA;
+        const char *k = getenv("W2XC_WINO_KERNEL");
+        return (k && atoi(k) == 16) ? (int)MID_WINO16 : (int)MID_WINO32;   // (until conv3x3_wino16 is the faster one on every shape)
+    }();
+    switch (o.kernel) {
+    case W2XC_KERNEL_MFMA: return MID_MFMA;
+    case W2XC_KERNEL_WINOGRAD: return MID_WINO16;
+    case W2XC_KERNEL_WINOGRAD32: return MID_WINO32;
+    default: return env_default;
+    }
+}
+bool mid_variant_applies(int midv, int cin, int cout)
+{
+    return midv == MID_WINO32 ? w2xc_wino_supported(cin, cout) : midv == MID_WINO16 ? w2xc_wino16_supported(cin, cout) : false;
 }
 
-int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, bool profile)
+int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
 {
     DevLayer &dl = c->layers[l];
     d.cin = m->layers[l].nin;
@@ -438,24 +458,28 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
-    const bool wino = kind == W2XC_K_MFMA && wino_enabled() && w2xc_wino_supported(d.cin, d.cout);
+    const int midv = kind == W2XC_K_MFMA ? mid_variant(o) : MID_MFMA;
+    const bool wino = midv != MID_MFMA && mid_variant_applies(midv, d.cin, d.cout);
     if (wino) {
-        if (!dl.w_wino) {
+        float *&img = midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
+        if (!img) {
             std::vector<float> pk(w2xc_wino_packed_floats(d.cin, d.cout));
-            w2xc_wino_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
-            int rc = upload(pk, &dl.w_wino);
+            if (midv == MID_WINO16) w2xc_wino16_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
+            else w2xc_wino_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
+            int rc = upload(pk, &img);
             if (rc) return rc;
         }
-        d.wpk = dl.w_wino;
+        d.wpk = img;
     }
     d.bias = dl.bias;
     ProfEvent ev;
+    const bool profile = o.profile != 0;
     if (profile) { int rc = prof_begin(c, l, st, &ev); if (rc) return rc; }
     hipError_t e = kind == W2XC_K_MID_SPLIT     ? w2xc_launch_split_mid(d, st)
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                    : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
-                   : wino                        ? w2xc_launch_wino(d, st)
+                   : wino                        ? (midv == MID_WINO16 ? w2xc_launch_wino16(d, st) : w2xc_launch_wino(d, st))
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -645,7 +669,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     dd.out_h = g1 - g_done;
                     dd.off_y = d.off_y + g_done;
                     dd.out = d.out + (size_t)g_done * d.out_rs;  // (plane / half strides stay those of the whole band)
-                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o.profile != 0);
+                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o);
                     if (rc) return rc;
                     g_done = g1;
                     W2xcConvDesc dg;
@@ -656,7 +680,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     dg.out_h = r1 - r0; dg.out_w = w;
                     dg.out = d_out + (size_t)(y0 - ra + r0) * out_stride_f;
                     dg.out_rs = (long long)out_stride_f; dg.out_ps = 1; dg.out_cs = out_cs;
-                    rc = launch_layer(c, m, n - 1, W2XC_K_LAST_GATHER, dg, st, o.profile != 0);
+                    rc = launch_layer(c, m, n - 1, W2XC_K_LAST_GATHER, dg, st, o);
                     if (rc) return rc;
                     rc = hk->output_ready(y0 + r0, y0 + r1);
                     if (rc) return rc;
@@ -679,7 +703,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     const int vlast = std::min(std::max(c0 + dd.out_h - 1 + 2 + d.off_y, 0), d.in_h - 1);   // last view row this chunk reads
                     int rc = hk->input_upto(vlast);
                     if (rc) return rc;
-                    rc = launch_layer(c, m, 0, kind, dd, st, o.profile != 0);
+                    rc = launch_layer(c, m, 0, kind, dd, st, o);
                     if (rc) return rc;
                 }
                 src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs; src_halves = d.halves;
@@ -701,13 +725,13 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     dd.out = d.out + (size_t)c0 * d.out_rs;
                     if (kind == W2XC_K_LAST_GATHER) dd.in = d.in + (size_t)c0 * d.in_rs;   // no offsets in that kernel
                     else dd.off_y = d.off_y + c0;
-                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o.profile != 0);
+                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o);
                     if (rc) return rc;
                     if (hk->output_ready) { rc = hk->output_ready(y0 + c0, y0 + c0 + dd.out_h); if (rc) return rc; }
                 }
                 break;
             }
-            int rc = launch_layer(c, m, k - 1, kind, d, st, o.profile != 0);
+            int rc = launch_layer(c, m, k - 1, kind, d, st, o);
             if (rc) return rc;
             if (hk && k == n && direct_out && hk->output_ready) { rc = hk->output_ready(y0, y1); if (rc) return rc; }
             if (k == n && !direct_out) {
@@ -1455,7 +1479,9 @@ int filter_on_device(w2xc_model *m, DevCtx *c, int layer, const float *in, long 
         if (rc) return rc;
         d.out = fc.nhwc[ob]; d.out_rs = (long long)w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
     }
-    int r = launch_layer(c, m, layer, kind, d, st, false);
+    w2xc_opts of = o;
+    of.profile = 0;
+    int r = launch_layer(c, m, layer, kind, d, st, of);
     if (r) return r;
     if (!direct_out) HIP_TRY(w2xc_launch_repack(d.out, d.out_rs, d.out_ps, 1, out, out_rs, out_ps, out_cs, h, w, hl.nout, st));
     if (res_nhwc) *res_nhwc = !direct_out;
@@ -1884,7 +1910,10 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     if (!m || layer < 0 || layer >= (int)m->layers.size()) return "";
     const w2xc_opts o = resolve_opts(opts);
     const W2xcKernelKind k = layer_kind(m, layer, o);
-    if (k == W2XC_K_MFMA && wino_enabled() && w2xc_wino_supported(m->layers[layer].nin, m->layers[layer].nout)) return "conv3x3_wino";
+    if (k == W2XC_K_MFMA) {
+        const int midv = mid_variant(o);
+        if (midv != MID_MFMA && mid_variant_applies(midv, m->layers[layer].nin, m->layers[layer].nout)) return midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
+    }
     return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
 }
 

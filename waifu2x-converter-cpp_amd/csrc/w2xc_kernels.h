@@ -78,6 +78,11 @@ bool w2xc_wino_supported(int cin, int cout);
 size_t w2xc_wino_packed_floats(int cin, int cout);
 void w2xc_wino_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
+// the same layer on v_mfma_f32_16x16x4_f32 with 128 accumulators per wave and two workgroups per CU (w2xc_wino16.hip);
+// d.wpk = the w2xc_wino16_pack image (16 * cin * cout floats, another fragment order)
+bool w2xc_wino16_supported(int cin, int cout);
+void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
+hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
 
 // split kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` 16-bit terms of every weight in
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.
