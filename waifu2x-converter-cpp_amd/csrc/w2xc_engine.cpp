@@ -397,7 +397,7 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 //   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two workgroups per CU (round 3)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
-// _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel if W2XC_WINO_KERNEL=16.
+// _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel unless W2XC_WINO_KERNEL=32.
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2 };
 int mid_variant(const w2xc_opts &o)
 {
@@ -405,7 +405,7 @@ int mid_variant(const w2xc_opts &o)
         const char *e = getenv("W2XC_WINOGRAD");
         if (e && atoi(e) == 0) return (int)MID_MFMA;
         const char *k = getenv("W2XC_WINO_KERNEL");
-        return (k && atoi(k) == 16) ? (int)MID_WINO16 : (int)MID_WINO32;   // (until conv3x3_wino16 is the faster one on every shape)
+        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (int)MID_WINO16;
     }();
     switch (o.kernel) {
     case W2XC_KERNEL_MFMA: return MID_MFMA;
@@ -414,9 +414,12 @@ int mid_variant(const w2xc_opts &o)
     default: return env_default;
     }
 }
-bool mid_variant_applies(int midv, int cin, int cout)
+// the variant that really runs a (cin, cout) layer: conv3x3_wino16 needs two 32-plane groups (cout >= 64), the other Winograd kernel takes the rest
+int mid_variant_for(int midv, int cin, int cout)
 {
-    return midv == MID_WINO32 ? w2xc_wino_supported(cin, cout) : midv == MID_WINO16 ? w2xc_wino16_supported(cin, cout) : false;
+    if (midv == MID_WINO16 && !w2xc_wino16_supported(cin, cout)) midv = MID_WINO32;
+    if (midv == MID_WINO32 && !w2xc_wino_supported(cin, cout)) midv = MID_MFMA;
+    return midv;
 }
 
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
@@ -458,8 +461,8 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
-    const int midv = kind == W2XC_K_MFMA ? mid_variant(o) : MID_MFMA;
-    const bool wino = midv != MID_MFMA && mid_variant_applies(midv, d.cin, d.cout);
+    const int midv = kind == W2XC_K_MFMA ? mid_variant_for(mid_variant(o), d.cin, d.cout) : MID_MFMA;
+    const bool wino = midv != MID_MFMA;
     if (wino) {
         float *&img = midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
         if (!img) {
@@ -1911,8 +1914,8 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     const w2xc_opts o = resolve_opts(opts);
     const W2xcKernelKind k = layer_kind(m, layer, o);
     if (k == W2XC_K_MFMA) {
-        const int midv = mid_variant(o);
-        if (midv != MID_MFMA && mid_variant_applies(midv, m->layers[layer].nin, m->layers[layer].nout)) return midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
+        const int midv = mid_variant_for(mid_variant(o), m->layers[layer].nin, m->layers[layer].nout);
+        if (midv != MID_MFMA) return midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
     }
     return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
 }

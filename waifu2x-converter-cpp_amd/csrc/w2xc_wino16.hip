@@ -1,5 +1,5 @@
 // w2xc_wino16.hip -- conv3x3_wino16: the 3x3 x Cin x Cout contraction of Model::filterWorker
-// (/root/reference/src/modelHandler.cpp:117-159) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32, two workgroups per CU.
+// (/root/reference/src/modelHandler.cpp:117-159) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD.
 //
 // Same algebra as conv3x3_wino (w2xc_wino.hip):  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 2x2 output block, the 16 positions xi of
 // the transformed domain being 16 independent GEMMs  M_xi[o][t] = sum_c U_xi[o][c] V_xi[c][t]  (o = output plane, t = block,
@@ -9,23 +9,27 @@
 //                  one-wave-per-SIMD kernel.  Whatever the wave issues besides MFMAs (patch reads, the transform's additions, the
 //                  transfers, the whole epilogue) is time the matrix pipe of that SIMD idles: measured 0.55-0.72 of the MFMA peak.
 //   conv3x3_wino16 16x16x4 MFMA (same rate, 32 cycles): a wave owns 32 planes x 16 blocks x 16 xi = 128 accumulators, so TWO waves
-//                  fit a SIMD -- and they come from two INDEPENDENT 4-wave workgroups (<= 80 KiB of LDS each), which drift apart
-//                  by construction: one workgroup's epilogue, barrier wait or stage head runs under the other one's MFMAs.
+//                  fit a SIMD.  The workgroup is 8 waves = 2 PLANE GROUPS x 4 block rows: both groups work on the same pixel tile
+//                  (one tile transfer serves 64 output planes) and group 1 runs ONE STAGE BEHIND group 0, so that a group's
+//                  epilogue and stage head run under the other group's MFMAs instead of beside its epilogue.
 //
-//   Work item  8 rows x 32 pixels of output (4 x 16 blocks) x one block of 32 output planes; wave w owns block row w.
+//   Work item  8 rows x 32 pixels of output (4 x 16 blocks) x 64 output planes; wave (g, w): plane group g, block row w.
 //              Lane (t = lane & 15, k = lane >> 4): block t of the row; K index k of the MFMA = channels 2k, 2k+1 of a slice.
-//   Stage      one 8-channel slice: 2 steps (channel 2k + st in lane quarter k) x 16 xi x 2 plane tiles = 64 MFMAs = 2048 cycles.
-//              A lane reads its 4x4 patch once per stage (16 ds_read_b64 = both channels), transforms both channels with packed
-//              additions, and every V value feeds two MFMAs (plane tiles 0 and 1).  The patch of stage s+1 is read and transformed
-//              under the MFMAs of stage s.
-//   LDS        A[3] x 12 KiB: the 10 x 34 pixel halo tile of a slice (32 B per pixel) by LDS-DMA, three stages deep, laid out
-//              [row][16-byte chunk 0/1][column parity][17 columns]: the 16 lanes of a quarter read 16 CONSECUTIVE 16-byte
-//              entries and the two quarters of a ds_read_b64 lane group take the two halves of them -- conflict-free without
-//              a swizzle, and every patch element is ONE base register + an immediate offset.
-//              U[2] x 16 KiB: the weights of (plane block, slice) in fragment order [step][plane tile][xi/4][lane][xi%4].
-//              + 3 KiB per-lane transfer offsets + bias.  72 KiB per workgroup.
-//   Transfers  SGPR base + 32-bit lane offset (no 64-bit VALU address per piece); per wave and stage 4 U pieces (one stage ahead)
-//              then 3 tile pieces (three stages ahead); the stage closes with a COUNTED vmcnt that leaves the tile pieces in flight.
+//   Stage      one 8-channel slice: 2 steps (channel 2k + st in lane quarter k) x 16 xi x 2 plane tiles = 64 MFMAs = 2048 cycles
+//              per wave.  A lane reads its 4x4 patch once per stage (16 ds_read_b64 = both channels), transforms both channels with
+//              packed additions, and every V value feeds two MFMAs (plane tiles 0 and 1).  The patch of stage s+1 is read and
+//              transformed under the MFMAs of stage s.
+//   LDS        A[3] x 27 KiB: the 10 x 34 pixel halo tile of a 16-CHANNEL slice (two stages), pixel-major: a pixel's four 16-byte
+//              chunks + one pad slot = 80 B, pixels of a row even columns first, then odd ones.  The 80-byte stride makes the 16
+//              lanes of a quarter (blocks 2 pixels apart = consecutive positions) hit 16 different bank quads (5 t mod 16), the
+//              quarter pairs of a ds_read_b64 lane group take the two halves: conflict-free, ONE base register + immediates.
+//              And a transfer instruction's 64 lanes cover 13 pixels x 64 contiguous bytes (the first version's channel-major
+//              layout touched 64 different cache lines per instruction: 1.9 of its 10.7 ms on 128->128).
+//              U[2 groups][2] x 16 KiB: the weights of (plane block, slice) in fragment order [step][plane tile][xi/4][lane][xi%4].
+//              + 8 KiB per-lane transfer offsets + 1 KiB dump + bias: 155 KiB, one workgroup per CU.
+//   Transfers  SGPR base + 32-bit lane offset; per wave and stage 4 U pieces (own group, one stage ahead), and every second stage 4 tile
+//              pieces (two 16-channel slices ahead, both groups in the same global stage); U first, tile pieces last, so the stage's
+//              closing COUNTED vmcnt leaves the tile pieces in flight.
 //   Epilogue   output transform, bias, LeakyReLU, 16-byte NHWC stores (a lane holds 4 consecutive planes of its block's 4 pixels).
 //   Banding    blocks sit on EVEN rows of the layer's whole output (W2xcConvDesc::wino_py), as in conv3x3_wino.
 #include "w2xc_kernels.h"
@@ -40,57 +44,68 @@
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
-// 4 = no epilogue stores, 8 = no stage barrier
+// 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
+// 64 = patch reads but no transform additions; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
 template <int CIN, int COUT, int ABL = 0>
-__global__ void __launch_bounds__(256, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
+__global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
 {
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2;
-    constexpr int NSL = CIN / 8, NOB = COUT / 32, NW = 4;
-    constexpr int ROW_SLOTS = 4 * 17;                       // 16-byte slots of one halo row: [chunk 2][parity 2][17]
-    constexpr int A_SLOTS = HH * ROW_SLOTS;                 // 680
-    constexpr int APW = (A_SLOTS + NW * 64 - 1) / (NW * 64);   // 3 pieces of 1 KiB per wave
-    constexpr int A_PIECES = APW * NW;                      // 12 (the last one only re-reads the tile's last slot: no wave-dependent branch)
+    constexpr int NSL = CIN / 8;                            // stages (8-channel slices) per item
+    constexpr int NSP = CIN / 16;                           // 16-channel tile slices per item
+    constexpr int NOB = COUT / 64;                          // 64-plane blocks
+    constexpr int NW = 8;
+    constexpr int PIX = 5;                                  // 16-byte slots per pixel: 4 chunks + 1 pad (80-byte stride)
+    constexpr int A_SLOTS = HH * HW * PIX;                  // 1700
+    constexpr int A_PIECES = (A_SLOTS + 63) / 64;           // 27 pieces of 1 KiB
+    constexpr int APW = (A_PIECES + NW - 1) / NW;           // 4 per wave; pieces >= A_PIECES land in the dump KiB
     constexpr unsigned A_BYTES = A_PIECES * 1024;
+    constexpr unsigned DUMP_BASE = 3 * A_BYTES;
+    constexpr unsigned U_BASE = DUMP_BASE + 1024;
     constexpr unsigned U_BYTES = 16 * 1024;
-    constexpr unsigned U_BASE = 3 * A_BYTES;
-    constexpr unsigned LOFS_BASE = U_BASE + 2 * U_BYTES;
-    constexpr unsigned BIAS_BASE = LOFS_BASE + APW * 256 * 4;
-    static_assert(CIN % 8 == 0 && NSL >= 4 && COUT % 32 == 0, "planes");
+    constexpr unsigned LOFS_BASE = U_BASE + 4 * U_BYTES;
+    constexpr unsigned BIAS_BASE = LOFS_BASE + APW * 512 * 4;
+    static_assert(CIN % 16 == 0 && NSP >= 2 && COUT % 64 == 0, "planes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, brow = wave & 3;
     const int t = lane & 15, k = lane >> 4;
 
-    // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the item list
+    // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the item list; this workgroup's items are
+    // item_of(0), item_of(1), ... (both plane groups walk the same list, group 1 one stage behind)
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const int cq = nitems >> 3, cr = nitems & 7;
     const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
     const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
-    int item = chunk_begin + (blockIdx.x >> 3);
-    if (item >= chunk_end) return;
+    const int item0 = chunk_begin + (blockIdx.x >> 3);
+    if (item0 >= chunk_end) return;
+    const int nmy = (chunk_end - item0 + per - 1) / per;
+    auto item_of = [&](int n) { return item0 + (n < nmy ? n : nmy - 1) * per; };   // (past the end: the last item again, harmless)
 
-    // ---- tile transfers: slot s of a slice <- pixel (row, col), chunk c4 ----
-    auto slot_of = [&](int jj, int &row, int &col, int &c4) {
+    // ---- tile transfers: slot s of a 16-channel slice <- pixel (row, col), chunk ch ----
+    auto slot_of = [&](int jj, int &row, int &col, int &ch) {
         int s = (jj * NW + wave) * 64 + lane;
         s = s < A_SLOTS ? s : A_SLOTS - 1;                  // slots past the tile re-read its last one
-        row = s / ROW_SLOTS;
-        const int rem = s - row * ROW_SLOTS;
-        c4 = rem / 34;
-        const int rem2 = rem - c4 * 34;
-        const int par = rem2 / 17;
-        col = 2 * (rem2 - par * 17) + par;
+        const int pos = s / PIX;
+        ch = s - pos * PIX;
+        ch = ch < 4 ? ch : 3;                               // the pad slot re-reads chunk 3 (same cache line)
+        row = pos / HW;
+        const int rem = pos - row * HW;
+        const int par = rem / 17;
+        col = 2 * (rem - par * 17) + par;
     };
-    for (int c = threadIdx.x; c < COUT; c += 256) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
+    for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
     {
+        // (row, col, chunk) of this lane's slots, packed, parked in LDS: as loop-invariant registers they are 12 VGPRs the stages need
         unsigned *lofs = reinterpret_cast<unsigned *>(const_cast<char *>(ldsb) + LOFS_BASE);
 #pragma unroll
         for (int jj = 0; jj < APW; jj++) {
-            int row, col, c4;
-            slot_of(jj, row, col, c4);
-            lofs[jj * 256 + threadIdx.x] = (unsigned)(((long long)row * d.in_rs + (long long)col * CIN + 4 * c4) * 4);   // bytes
+            int row, col, ch;
+            slot_of(jj, row, col, ch);
+            lofs[jj * 512 + threadIdx.x] = (unsigned)(row | (col << 8) | (ch << 16));
         }
     }
     // The transfer source of (item, slice) = wave-uniform 64-bit base (tile origin, clamped into the plane) + voff[jj] (32-bit, per lane)
@@ -102,32 +117,40 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino16(W2xcConvDesc d, int til
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
         const int yb = clampi(y0, 0, d.in_h - 1), xb = clampi(x0, 0, d.in_w - 1);
         a_base = reinterpret_cast<const char *>(d.in) + ((long long)yb * d.in_rs + (long long)xb * CIN) * 4;
-        if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
-            const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
-#pragma unroll
-            for (int jj = 0; jj < APW; jj++) voff[jj] = lofs[jj * 256 + threadIdx.x];
-            return;
-        }
+        const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
+        const int rs4 = (int)d.in_rs * 4;   // (a tile spans 10 rows: the byte offsets fit 32 bits for any plane the engine accepts)
 #pragma unroll
         for (int jj = 0; jj < APW; jj++) {
-            int row, col, c4;
-            slot_of(jj, row, col, c4);
+            const unsigned pk = lofs[jj * 512 + threadIdx.x];
+            const int row = pk & 255, col = (pk >> 8) & 255, ch = pk >> 16;
             const int gy = clampi(y0 + row, 0, d.in_h - 1) - yb;
             const int gx = clampi(x0 + col, 0, d.in_w - 1) - xb;
-            voff[jj] = (unsigned)(((long long)gy * d.in_rs + (long long)gx * CIN + 4 * c4) * 4);
+            voff[jj] = (unsigned)(gy * rs4 + (gx * CIN + 4 * ch) * 4);
         }
     };
-    // tile piece jj of slice sl_ -> tile slot `slot`
-    auto dma_a = [&](int sl_, unsigned slot, int jj) {
-        const char *sbase = a_base + sl_ * 32;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + slot * A_BYTES + (unsigned)(jj * NW + wave) * 1024u);
+    // tile-transfer cursor: the next 16-channel slice to fetch is slice a_lp of item_of(a_n), into tile buffer a_buf (0, 1, 2, 0, ...).
+    // Both plane groups advance it in the same global stage.
+    int a_n = 0, a_lp = 0;
+    unsigned a_buf = 0;
+    auto dma_a = [&](int jj) {
+        const char *sbase = a_base + a_lp * 64;
+        const int piece = jj * NW + wave;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(piece < A_PIECES ? lds0 + a_buf * A_BYTES + (unsigned)piece * 1024u : lds0 + DUMP_BASE);
         lds_dma16_s<0>(sbase, voff[jj], dst);
     };
-    // U of (plane block ob, slice sl_): 16 pieces of 1 KiB, 4 per wave
+    auto a_advance = [&]() {
+        a_buf = a_buf == 2 ? 0u : a_buf + 1u;
+        if (++a_lp == NSP) {
+            a_lp = 0;
+            a_n++;
+            tile_offsets(item_of(a_n));
+        }
+    };
+    // U of (32-plane block ob, slice sl_): 16 pieces of 1 KiB, 4 per wave of the group
     const unsigned b_voff = (unsigned)lane * 16u;
     auto dma_b = [&](int ob, int sl_, unsigned slot, int jb) {
-        const char *sbase = reinterpret_cast<const char *>(d.wpk) + ((size_t)(ob * NSL + sl_) * 16 + wave * 4) * 1024;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + U_BASE + slot * U_BYTES + (unsigned)(wave * 4) * 1024u);
+        const char *sbase = reinterpret_cast<const char *>(d.wpk) + ((size_t)(ob * NSL + sl_) * 16 + brow * 4) * 1024;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + U_BASE + ((unsigned)grp * 2u + slot) * U_BYTES + (unsigned)(brow * 4) * 1024u);
         switch (jb) {
         case 0: lds_dma16_s<0>(sbase, b_voff, dst); break;
         case 1: lds_dma16_s<1024>(sbase, b_voff, dst); break;
@@ -137,183 +160,232 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino16(W2xcConvDesc d, int til
     };
 
     // ---- fragment addressing ----
-    // patch element (r, c) of this lane's block: halo pixel (2w + r, 2t + c), channels 2k, 2k+1 of the slice = chunk k >> 1, half k & 1:
-    //   byte ((2w + r) * 68 + (k >> 1) * 34 + (c & 1) * 17 + t + (c >> 1)) * 16 + 8 * (k & 1)   -- base + immediate
-    const unsigned pbase = (unsigned)(((2 * wave) * ROW_SLOTS + (k >> 1) * 34 + t) * 16 + 8 * (k & 1));
-    constexpr unsigned P_ROW = ROW_SLOTS * 16, P_PAR = 17 * 16;
-    const unsigned ubase = U_BASE + (unsigned)lane * 16u;
+    // patch element (r, c) of this lane's block: halo pixel (2w + r, 2t + c) at position (2w + r) * 34 + (c & 1) * 17 + t + (c >> 1) of
+    // the tile, channels 2k, 2k+1 of 8-channel sub-slice `sub` = chunk 2 sub + (k >> 1), half k & 1:   base + immediate
+    constexpr unsigned P_E = PIX * 16, P_ROW = HW * P_E, P_PAR = 17 * P_E;
+    const unsigned pbase = (unsigned)(((2 * brow) * HW + t) * P_E + (k >> 1) * 16 + (k & 1) * 8);
+    const unsigned ubase = U_BASE + (unsigned)grp * 2u * U_BYTES + (unsigned)lane * 16u;
 
-    f32x2v va[16], vb[16]; // V of the stage being multiplied / of the next one (roles alternate): [xi] = (channel 2k, channel 2k+1)
-    f32x2v raw[16], tq[4][4];
-    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], columns of d first
+    // V of the stage being multiplied / of the next one (roles alternate): [channel 2k + s][xi].  Plain floats and SCALAR additions:
+    // v_pk_add_f32 beside MFMAs costs the matrix pipe ~6 cycles apiece (measured: the packed transform was 0.8 of 9.7 ms on 128->128).
+    struct VSet { float s[2][16]; };
+    VSet va, vb;
+    f32x2v raw[16];
+    float tq[2][4][4];
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], columns of d first -- as 64 single additions (op = channel h, output
+    // row i, column c), each pinned where it is written: the results are first used a stage later and LLVM otherwise sinks the
+    // additions there, out of the MFMA shadows (or re-packs them)
+    auto col_op = [&](int h, int i, int c) {
+        const float d0 = raw[0 * 4 + c][h], d1 = raw[1 * 4 + c][h], d2 = raw[2 * 4 + c][h], d3 = raw[3 * 4 + c][h];
+        float r = i == 0 ? d0 - d2 : i == 1 ? d1 + d2 : i == 2 ? d2 - d1 : d1 - d3;
+        asm volatile("" : "+v"(r));
+        tq[h][i][c] = r;
+    };
+    auto row_op = [&](VSet &v, int h, int r, int j) {
+        float x = j == 0 ? tq[h][r][0] - tq[h][r][2] : j == 1 ? tq[h][r][1] + tq[h][r][2] : j == 2 ? tq[h][r][2] - tq[h][r][1] : tq[h][r][1] - tq[h][r][3];
+        asm volatile("" : "+v"(x));
+        v.s[h][r * 4 + j] = x;
+    };
     auto transform_cols = [&](int c) {
-        const f32x2v d0 = raw[0 * 4 + c], d1 = raw[1 * 4 + c], d2 = raw[2 * 4 + c], d3 = raw[3 * 4 + c];
-        tq[0][c] = d0 - d2;
-        tq[1][c] = d1 + d2;
-        tq[2][c] = d2 - d1;
-        tq[3][c] = d1 - d3;
-        // (pinned: the results are first used a stage later, and LLVM sinks the additions there -- out of the MFMA shadows -- otherwise)
-        asm volatile("" : "+v"(tq[0][c]), "+v"(tq[1][c]), "+v"(tq[2][c]), "+v"(tq[3][c]));
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) col_op(h, i, c);
     };
-    auto transform_rows = [&](f32x2v (&v)[16], int r) {
-        v[r * 4 + 0] = tq[r][0] - tq[r][2];
-        v[r * 4 + 1] = tq[r][1] + tq[r][2];
-        v[r * 4 + 2] = tq[r][2] - tq[r][1];
-        v[r * 4 + 3] = tq[r][1] - tq[r][3];
-        asm volatile("" : "+v"(v[r * 4 + 0]), "+v"(v[r * 4 + 1]), "+v"(v[r * 4 + 2]), "+v"(v[r * 4 + 3]));
+    auto transform_rows = [&](VSet &v, int r) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) row_op(v, h, r, j);
     };
 
-    // ---- prologue: tile slices 0..2 and U(slice 0) of the first item; V of its first stage ----
-    tile_offsets(item);
+    // ---- prologue: tile slices 0 and 1 of the first item, U(slice 0) of both groups ----
+    tile_offsets(item_of(0));
 #pragma unroll
-    for (int s = 0; s < 3; s++)
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
-        for (int jj = 0; jj < APW; jj++) dma_a(s, (unsigned)s, jj);
+        for (int jj = 0; jj < APW; jj++) dma_a(jj);
+        a_advance();
+    }
 #pragma unroll
-    for (int jb = 0; jb < 4; jb++) dma_b(item % NOB, 0, 0, jb);
+    for (int jb = 0; jb < 4; jb++) dma_b((item_of(0) % NOB) * 2 + grp, 0, 0, jb);
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(ldsb + pbase + r * P_ROW + (c & 1) * P_PAR + (c >> 1) * 16);
-#pragma unroll
-    for (int c = 0; c < 4; c++) transform_cols(c);
-#pragma unroll
-    for (int r = 0; r < 4; r++) transform_rows(va, r);
 
-    unsigned aslot = 0;    // tile slot of the CURRENT stage's slice (its patch was read one stage ago); runs 0, 1, 2, 0, ... over all stages
-    unsigned uslot = 0;
-    for (;;) {
-        const int item_n = item + per < chunk_end ? item + per : item;   // (the last item prefetches itself: harmless)
-        // The accumulators are DEFINED by the first stage of an item (C = 0) and die in its epilogue
-        f32x4 acc[16][2];
-        auto stage = [&](auto FIRST, int sl, f32x2v (&vcur)[16], f32x2v (&vnext)[16]) {
-            constexpr bool first = decltype(FIRST)::value;
-            // transfers of this stage: U of the next stage, tile slice of the stage three ahead
-            int u_ob = item % NOB, u_sl = sl + 1;
-            if (sl == NSL - 1) { u_ob = item_n % NOB; u_sl = 0; }
-            int a_sl = sl + 3;
-            if (sl == NSL - 3) tile_offsets(item_n);          // from here on the tile prefetch runs in the next item
-            if (sl >= NSL - 3) a_sl = sl + 3 - NSL;
-            const unsigned a_dst = aslot;                      // slice (stage + 3) replaces the slice whose patch was read a stage ago
-            const unsigned a_src = aslot == 2 ? 0u : aslot + 1u;   // slice (stage + 1): transformed during this stage
-            const char *pa = ldsb + a_src * A_BYTES + pbase;
-            const char *ua = ldsb + ubase + uslot * U_BYTES;
-            f32x4 u[2][2];
-            u[0][0] = *reinterpret_cast<const f32x4 *>(ua + 0 * 1024);
-            u[0][1] = *reinterpret_cast<const f32x4 *>(ua + 4 * 1024);
-            static_for<0, 64>([&](auto SLOT) {
-                constexpr int slot = decltype(SLOT)::value;
-                constexpr int st = slot >> 5, g = slot >> 3, x4 = (slot >> 1) & 3, pt = slot & 1, xi = ((slot >> 3) & 3) * 4 + x4;
-                if constexpr (first && st == 0) {
-                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                    acc[xi][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g & 1][pt][x4], vcur[xi][st], z, 0, 0, 0);
-                } else {
-                    acc[xi][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g & 1][pt][x4], vcur[xi][st], acc[xi][pt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- fillers, a few per MFMA ----
-                // U fragments of the next group of 8 MFMAs (group g = (step, xi/4); [step][plane tile][xi/4] KiB in the U slot)
-                if constexpr ((slot & 7) == 1 && g < 7) {
-                    constexpr int gn = g + 1;
-                    u[gn & 1][0] = *reinterpret_cast<const f32x4 *>(ua + (((gn >> 2) * 2 + 0) * 4 + (gn & 3)) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr ((slot & 7) == 5 && g < 7) {
-                    constexpr int gn = g + 1;
-                    u[gn & 1][1] = *reinterpret_cast<const f32x4 *>(ua + (((gn >> 2) * 2 + 1) * 4 + (gn & 3)) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the next stage's patch, column by column (slots 0..15), its transform behind it (columns 8..23, rows 24..39)
-                if constexpr (slot < 16) {
-                    constexpr int r = slot & 3, c = slot >> 2;
-                    raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(pa + r * P_ROW + (c & 1) * P_PAR + (c >> 1) * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (slot >= 8 && slot < 24 && (slot & 3) == 3) {
-                    transform_cols((slot - 8) >> 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (slot >= 24 && slot < 40 && (slot & 3) == 3) {
-                    transform_rows(vnext, (slot - 24) >> 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // transfers: U pieces first, tile pieces last (the stage's closing wait leaves the tile pieces in flight)
-                if constexpr (slot == 18 || slot == 26 || slot == 34 || slot == 42) {
-                    if constexpr (!(ABL & 1)) dma_b(u_ob, u_sl, uslot ^ 1u, (slot - 18) >> 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (slot == 46 || slot == 52 || slot == 58) {
-                    if constexpr (!(ABL & 2)) dma_a(a_sl, a_dst, (slot - 46) / 6);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-            // U(next stage) and the tile slice two stages ahead have landed; this stage's tile pieces (the youngest) may still fly
+    // The rest runs once per plane group, with the group as a compile-time constant: the groups differ in WHICH stages carry
+    // the tile transfers (the same global stage = even stages of group 0, odd ones of group 1), and a run-time branch inside
+    // a stage costs a wait-everything at every join.
+    auto run = [&](auto GRP) {
+        constexpr int G = decltype(GRP)::value;
+        // V of stage 0 (group 1: under group 0's stage 0, with the tile transfers of that global stage)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(ldsb + pbase + r * P_ROW + (c & 1) * P_PAR + (c >> 1) * P_E);
+#pragma unroll
+        for (int c = 0; c < 4; c++) transform_cols(c);
+#pragma unroll
+        for (int r = 0; r < 4; r++) transform_rows(va, r);
+        if constexpr (G == 1) {
+#pragma unroll
+            for (int jj = 0; jj < APW; jj++) dma_a(jj);
+            a_advance();
             W2XC_WAIT_VMCNT(APW);
-            if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            aslot = a_src;
-            uslot ^= 1u;
-        };
-        stage(std::true_type{}, 0, va, vb);
-#pragma unroll 1
-        for (int sl = 1; sl < NSL - 1; sl += 2) {
-            stage(std::false_type{}, sl, vb, va);
-            stage(std::false_type{}, sl + 1, va, vb);
         }
-        stage(std::false_type{}, NSL - 1, vb, va);
-        {
-            // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
-            //      C/D of the 16x16 MFMA: lane & 15 = block, register e = plane 4 * (lane >> 4) + e of the plane tile ----
-            const int ob = item % NOB, ptile = item / NOB;
-            const int tile_y = ptile / tiles_x, tile_x = ptile - tile_y * tiles_x;
-            const int ty0 = tile_y * ROWS - d.wino_py;
-            const int oy = ty0 + 2 * wave, ox = tile_x * 32 + 2 * t;
-            float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * k;
-            const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
-#pragma unroll
-            for (int pt = 0; pt < 2; pt++) {
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + (ob * 32 + 16 * pt + 4 * k) * 4);
-                f32x4 y[2][2];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float tm[2][4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        tm[0][j] = acc[0 * 4 + j][pt][e] + acc[1 * 4 + j][pt][e] + acc[2 * 4 + j][pt][e];
-                        tm[1][j] = acc[1 * 4 + j][pt][e] - acc[2 * 4 + j][pt][e] - acc[3 * 4 + j][pt][e];
+
+        unsigned cbuf = 0;     // tile buffer of the CURRENT stage's 16-channel slice
+        unsigned uslot = 0;
+        for (int n = 0; n < nmy; n++) {
+            const int item = item_of(n), item_n = item_of(n + 1);
+            // The accumulators are DEFINED by the first stage of an item (C = 0) and die in its epilogue
+            f32x4 acc[16][2];
+            auto stage = [&](auto FIRST, auto ODD, int sl, VSet &vcur, VSet &vnext) {
+                constexpr bool first = decltype(FIRST)::value;
+                constexpr int odd = decltype(ODD)::value;               // sl & 1 (NSL is even: also the parity of the global stage count)
+                constexpr bool issue_a = (odd == G);                    // this stage carries tile transfers
+                // transfers of this stage: U of the next stage (own group)
+                int u_ob = (item % NOB) * 2 + G, u_sl = sl + 1;
+                if (sl == NSL - 1) { u_ob = (item_n % NOB) * 2 + G; u_sl = 0; }
+                // the next stage's patch: even stage -> second half of the current 16-channel slice; odd stage -> first half of the next one
+                const unsigned rbuf = odd ? (cbuf == 2 ? 0u : cbuf + 1u) : cbuf;
+                const char *pa = ldsb + rbuf * A_BYTES + pbase + (odd ? 0 : 32);
+                const char *ua = ldsb + ubase + uslot * U_BYTES;
+                f32x4 u[2][2];
+                u[0][0] = *reinterpret_cast<const f32x4 *>(ua + 0 * 1024);
+                u[0][1] = *reinterpret_cast<const f32x4 *>(ua + 4 * 1024);
+                static_for<0, 64>([&](auto SLOT) {
+                    constexpr int slot = decltype(SLOT)::value;
+                    constexpr int st = slot >> 5, g = slot >> 3, x4 = (slot >> 1) & 3, pt = slot & 1, xi = ((slot >> 3) & 3) * 4 + x4;
+                    if constexpr ((ABL & 128) != 0) {
+                        if constexpr (first && st == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[xi][pt]) : "v"(u[g & 1][pt][x4]), "v"(vcur.s[st][xi]));
+                        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[xi][pt]) : "v"(u[g & 1][pt][x4]), "v"(vcur.s[st][xi]));
+                    } else if constexpr (first && st == 0) {
+                        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                        acc[xi][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g & 1][pt][x4], vcur.s[st][xi], z, 0, 0, 0);
+                    } else {
+                        acc[xi][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g & 1][pt][x4], vcur.s[st][xi], acc[xi][pt], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const float y0 = tm[i][0] + tm[i][1] + tm[i][2] + bq[e];
-                        const float y1 = tm[i][1] - tm[i][2] - tm[i][3] + bq[e];
-                        y[i][0][e] = fmaxf(y0, 0.1f * y0);
-                        y[i][1][e] = fmaxf(y1, 0.1f * y1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- fillers: at most three non-MFMA instructions behind any MFMA ----
+                    // U fragments of the next group of 8 MFMAs (group g = (step, xi/4); [step][plane tile][xi/4] KiB in the U slot), read at the
+                    // head of group g: 8 MFMAs of cover
+                    if constexpr ((slot & 7) < 2 && g < 7 && !(ABL & 32)) {
+                        constexpr int gn = g + 1, p = slot & 7;
+                        u[gn & 1][p] = *reinterpret_cast<const f32x4 *>(ua + (((gn >> 2) * 2 + p) * 4 + (gn & 3)) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-                if constexpr ((ABL & 4) != 0) {
-                    if (y[0][0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0][0] + y[0][1] + y[1][0] + y[1][1];
-                } else if (interior) {
+                    // the next stage's patch, column by column, one read per MFMA (slots 2..7, 10..15, 18..21)
+                    if constexpr (slot >= 2 && slot < 22 && (slot & 7) >= 2 && !(ABL & 16)) {
+                        constexpr int idx = (slot >> 3) * 6 + (slot & 7) - 2;
+                        constexpr int r = idx & 3, c = idx >> 2;
+                        raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(pa + r * P_ROW + (c & 1) * P_PAR + (c >> 1) * P_E);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // its transform, two additions per MFMA: columns in slots 22..37, rows in 38..53
+                    if constexpr (slot >= 22 && slot < 38 && !(ABL & (16 | 64))) {
+                        constexpr int o = (slot - 22) * 2;          // op o, o+1 of 32: (c, h, i) = (o >> 3, (o >> 2) & 1, o & 3)
+                        col_op((o >> 2) & 1, o & 3, o >> 3);
+                        col_op(((o + 1) >> 2) & 1, (o + 1) & 3, (o + 1) >> 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (slot >= 38 && slot < 54 && !(ABL & (16 | 64))) {
+                        constexpr int o = (slot - 38) * 2;          // (r, h, j) = (o >> 3, (o >> 2) & 1, o & 3)
+                        row_op(vnext, (o >> 2) & 1, o >> 3, o & 3);
+                        row_op(vnext, ((o + 1) >> 2) & 1, (o + 1) >> 3, (o + 1) & 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // transfers: U pieces first, tile pieces last (the stage's closing wait leaves the tile pieces in flight)
+                    if constexpr (slot == 3 || slot == 7 || slot == 11 || slot == 15) {
+                        if constexpr (!(ABL & 1)) dma_b(u_ob, u_sl, uslot ^ 1u, (slot - 3) >> 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (issue_a && (slot == 55 || slot == 57 || slot == 59 || slot == 61)) {
+                        if constexpr (!(ABL & 2)) dma_a((slot - 55) >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                if constexpr (issue_a) a_advance();
+                // U(next stage) and every older tile piece have landed; this stage's tile pieces (the youngest) may still fly
+                if constexpr (issue_a && !(ABL & 2)) W2XC_WAIT_VMCNT(APW);
+                else W2XC_WAIT_VMCNT(0);
+                if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (odd) cbuf = rbuf;
+                uslot ^= 1u;
+            };
+            stage(std::true_type{}, std::integral_constant<int, 0>{}, 0, va, vb);
+#pragma unroll 1
+            for (int sl = 1; sl < NSL - 1; sl += 2) {
+                stage(std::false_type{}, std::integral_constant<int, 1>{}, sl, vb, va);
+                stage(std::false_type{}, std::integral_constant<int, 0>{}, sl + 1, va, vb);
+            }
+            stage(std::false_type{}, std::integral_constant<int, 1>{}, NSL - 1, vb, va);
+            {
+                // (the hazard recogniser does not see inside inline asm: let the last MFMAs drain before VALU reads their results)
+                if constexpr ((ABL & 128) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
+                //      C/D of the 16x16 MFMA: lane & 15 = block, register e = plane 4 * (lane >> 4) + e of the plane tile ----
+                const int ob = (item % NOB) * 2 + G, ptile = item / NOB;
+                const int tile_y = ptile / tiles_x, tile_x = ptile - tile_y * tiles_x;
+                const int ty0 = tile_y * ROWS - d.wino_py;
+                const int oy = ty0 + 2 * brow, ox = tile_x * 32 + 2 * t;
+                float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * k;
+                const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
+                for (int pt = 0; pt < 2; pt++) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + (ob * 32 + 16 * pt + 4 * k) * 4);
+                    f32x4 y[2][2];
+                    // two planes at a time: registers 2h, 2h+1 of an accumulator quad are a register PAIR (v_pk_add_f32 without moves)
 #pragma unroll
-                        for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
-                } else {
+                    for (int h = 0; h < 2; h++) {
+                        auto m = [&](int xi) { return f32x2v{acc[xi][pt][2 * h], acc[xi][pt][2 * h + 1]}; };
+                        const f32x2v b2 = {bq[2 * h], bq[2 * h + 1]};
+                        f32x2v tm[2][4];
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
+                        for (int j = 0; j < 4; j++) {
+                            tm[0][j] = m(0 * 4 + j) + m(1 * 4 + j) + m(2 * 4 + j);
+                            tm[1][j] = m(1 * 4 + j) - m(2 * 4 + j) - m(3 * 4 + j);
+                        }
 #pragma unroll
-                        for (int j = 0; j < 2; j++)
-                            if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w)
-                                *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
+                        for (int i = 0; i < 2; i++) {
+                            const f32x2v y0 = tm[i][0] + tm[i][1] + tm[i][2] + b2;
+                            const f32x2v y1 = tm[i][1] - tm[i][2] - tm[i][3] + b2;
+                            const f32x2v s0 = y0 * 0.1f, s1 = y1 * 0.1f;
+                            y[i][0][2 * h] = fmaxf(y0[0], s0[0]);
+                            y[i][0][2 * h + 1] = fmaxf(y0[1], s0[1]);
+                            y[i][1][2 * h] = fmaxf(y1[0], s1[0]);
+                            y[i][1][2 * h + 1] = fmaxf(y1[1], s1[1]);
+                        }
+                    }
+                    if constexpr ((ABL & 4) != 0) {
+                        if (y[0][0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0][0] + y[0][1] + y[1][0] + y[1][1];
+                    } else if (interior) {
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++)
+                                if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w)
+                                    *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
+                    }
                 }
             }
-            item += per;
-            if (item >= chunk_end) break;
         }
-    }
+        if constexpr (G == 0) {   // group 1's last stage
+            W2XC_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    if (grp == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
 }
 
@@ -322,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino16(W2xcConvDesc d, int til
 // ------------------------------------------------------------------------------------------------
 bool w2xc_wino16_supported(int cin, int cout)
 {
-    return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
+    return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);   // (32 output planes: one plane group only -- conv3x3_wino)
 }
 
 // wpk[plane block][slice (8 channels)][step st][plane tile pt][xi / 4][lane][xi % 4] = U_xi[o][c],  U = G g G^T
@@ -353,9 +425,9 @@ template <int CIN, int COUT, int ABL = 0>
 static hipError_t launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 1) + 7) / 8;
-    const int nitems = tiles_x * tiles_y * (COUT / 32);
-    constexpr size_t lds_bytes = 3 * (size_t)(12 * 1024) + 2 * (size_t)(16 * 1024) + 3 * 1024 + COUT * 4;   // tile ring + U ring + offset table + bias
-    static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
+    const int nitems = tiles_x * tiles_y * (COUT / 64);
+    constexpr size_t lds_bytes = 3 * (size_t)(27 * 1024) + 1024 + 4 * (size_t)(16 * 1024) + 4 * 512 * 4 + COUT * 4;   // tile ring + dump + U rings + offset table + bias
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_wino16<CIN, COUT, ABL>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
@@ -366,9 +438,9 @@ static hipError_t launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
         if (e != hipSuccess) return e;
         if (dev < 64) attr_done.fetch_or(1ull << dev);
     }
-    int grid = 512;   // two persistent workgroups per CU; a multiple of 8 (one share per XCD)
+    int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
     if (grid > ((nitems + 7) & ~7)) grid = (nitems + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, d, tiles_x, nitems);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, d, tiles_x, nitems);
     return hipGetLastError();
 }
 
@@ -387,21 +459,19 @@ hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
         case 4: return launch_wino16<128, 128, 4>(d, stream);
         case 7: return launch_wino16<128, 128, 7>(d, stream);
         case 15: return launch_wino16<128, 128, 15>(d, stream);
-        default: break;
-    }
-    if (d.cin == 32 && d.cout == 32) switch (abl) {
-        case 3: return launch_wino16<32, 32, 3>(d, stream);
-        case 4: return launch_wino16<32, 32, 4>(d, stream);
-        case 7: return launch_wino16<32, 32, 7>(d, stream);
+        case 23: return launch_wino16<128, 128, 23>(d, stream);
+        case 39: return launch_wino16<128, 128, 39>(d, stream);
+        case 55: return launch_wino16<128, 128, 55>(d, stream);
+        case 71: return launch_wino16<128, 128, 71>(d, stream);
+        case 128: return launch_wino16<128, 128, 128>(d, stream);
+        case 135: return launch_wino16<128, 128, 135>(d, stream);
+        case 151: return launch_wino16<128, 128, 151>(d, stream);
         default: break;
     }
 #endif
     switch (d.cin * 1000 + d.cout) {
-    case 32032:  return launch_wino16<32, 32>(d, stream);
     case 32064:  return launch_wino16<32, 64>(d, stream);
     case 32128:  return launch_wino16<32, 128>(d, stream);
-    case 64032:  return launch_wino16<64, 32>(d, stream);
-    case 128032: return launch_wino16<128, 32>(d, stream);
     case 64064:  return launch_wino16<64, 64>(d, stream);
     case 64128:  return launch_wino16<64, 128>(d, stream);
     case 128064: return launch_wino16<128, 64>(d, stream);
