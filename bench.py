@@ -31,12 +31,15 @@ Extra objects on the JSON line:
                pixel) / its average duration from hipEvents recorded on the launch stream (w2xc_opts.profile)
                in a second pass of the same K steps right after the timed region (so the events are not inside
                `value`'s region; `ms_per_step_profiled` shows they cost nothing), vs the 157.3 TFLOP/s fp32 MFMA peak.
-               Since round 2 that layer runs conv3x3_wino (Winograd F(2x2,3x3): 16 instead of 36 multiplies per
-               plane pair and 2x2 block, all fp32), so `frac` on algorithmic FLOPs can exceed 1; `executed_frac`
-               is the fraction of the MFMA peak the kernel's own 16/36 of those FLOPs reach (W2XC_WINOGRAD=0 in the
-               environment runs conv3x3_mfma2, where the two coincide).
+               That layer runs a Winograd kernel (conv3x3_wino16 / conv3x3_wino, F(2x2,3x3): 16 instead of 36 multiplies
+               per plane pair and 2x2 block, all fp32).  `achieved` / `frac` are what the MFMA pipe really does: the
+               FLOPs the kernel ISSUES (16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
+               reproducible from profiles/r3_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
+               time) is carried beside it as `algorithmic_tflops` / `algorithmic_speedup_vs_direct_roofline` (> 1 means
+               faster than ANY direct convolution could be on this MFMA).  w2xc_opts.kernel = W2XC_KERNEL_MFMA (or
+               W2XC_WINOGRAD=0) runs conv3x3_mfma2, where executed = algorithmic.
                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same command
-               (profiles/r2_roofline.json), only when that profile was taken from the kernel sources being run
+               (profiles/r3_roofline.json), only when that profile was taken from the kernel sources being run
                (hash check), else null.
   cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real binary cannot be
                built) timed on this host's cores on a bounded sample of whole 512^2 blocks of the same plane.
@@ -92,17 +95,17 @@ def pmc_traffic(kernel, cin, cout, H, W):
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/make_profile_summary.py).  rocprofv3 cannot
     run inside this process, so this is the profile of the SAME command -- valid only for the sources it was taken
     from: returns (bytes, note)."""
-    path = os.path.join(ROOT, "profiles", "r2_roofline.json")
+    path = os.path.join(ROOT, "profiles", "r3_roofline.json")
     try:
         prof = json.load(open(path))
     except Exception:
-        return None, "no committed PMC profile (profiles/r2_roofline.json)"
+        return None, "no committed PMC profile (profiles/r3_roofline.json)"
     if prof.get("kernel_source_hash") != kernel_source_hash():
         return None, "committed PMC profile is from other kernel sources (hash %s != %s): dropped" % (prof.get("kernel_source_hash"), kernel_source_hash())
     for name, k in prof.get("kernels", {}).items():
         if kernel in name and ("<%d, %d" % (cin, cout)) in name and k.get("pixels") == (H + 2) * (W + 2):
-            return int(k["hbm_traffic_bytes"]), "profiles/r2_roofline.json (rocprofv3 --pmc, same command, same sources)"
-    return None, "no matching kernel in profiles/r2_roofline.json"
+            return int(k["hbm_traffic_bytes"]), "profiles/r3_roofline.json (rocprofv3 --pmc, same command, same sources)"
+    return None, "no matching kernel in profiles/r3_roofline.json"
 
 
 def cpu_baseline(layers, plane, budget_s=15.0):
@@ -440,19 +443,23 @@ def main():
         # split modes: every algorithmic multiply-add is 3 (bf16x2, fp16x2) or 6 (bf16x3) 16-bit MFMA products
         products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "fp16x2": 3}[args.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
-        achieved = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        def issued(l):   # fraction of a layer's algorithmic multiplies its kernel issues (Winograd F(2x2,3x3): 16 of 36)
+            return 16.0 / 36.0 if "wino" in ms.kernel_name(l, opts) else 1.0
+        algorithmic = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        achieved = algorithmic * issued(dom)
         per_layer = []
         for l in range(n_layers):
             ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
             cin, cout = ms.planes(l)
             alg_bytes = (cin + cout) * 4 * flops_layer[l] / (18 * cin * cout)
+            alg_tf = products * flops_layer[l] / (ms_l * 1e-3) / 1e12 if ms_l > 0 else None
             per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l, opts), "planes": "%d->%d" % (cin, cout),
                               "ms": round(ms_l, 4),
-                              "tflops": round(flops_layer[l] / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None,
-                              "frac_of_peak": round(products * flops_layer[l] / (ms_l * 1e-3) / 1e12 / peak, 4) if ms_l > 0 else None,
-                              # (algorithmic FLOPs; conv3x3_wino issues 16/36 of them, so its MFMA-pipe share is:)
-                              "executed_frac_of_peak": round(products * flops_layer[l] / (ms_l * 1e-3) / 1e12 / peak *
-                                                             (16.0 / 36.0 if "wino" in ms.kernel_name(l, opts) else 1.0), 4) if ms_l > 0 else None,
+                              # what the MFMA pipe does: FLOPs the kernel issues / time, and its share of the peak
+                              "tflops": round(alg_tf * issued(l), 2) if ms_l > 0 else None,
+                              "frac_of_peak": round(alg_tf * issued(l) / peak, 4) if ms_l > 0 else None,
+                              # SURVEY 8(d)'s algorithmic FLOPs over the same time
+                              "algorithmic_tflops": round(alg_tf, 2) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
         traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
                                  if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else (None, "no PMC profile for this configuration"))
@@ -487,12 +494,14 @@ def main():
                          "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
-                         "avg_launch_ms": round(dom_ms, 4), "flops_per_launch": dom_flops, "mfma_products_per_fma": products,
-                         "executed_flops_per_launch": dom_flops * products * (16.0 / 36.0 if "wino" in ms.kernel_name(dom, opts) else 1.0),
-                         "executed_frac": round(achieved / peak * (16.0 / 36.0 if "wino" in ms.kernel_name(dom, opts) else 1.0), 4),
-                         "note": ("conv3x3_wino: Winograd F(2x2,3x3) does 16/36 of the algorithmic multiplies, so `achieved` / `frac` (algorithmic FLOPs "
-                                  "over time, the contract's definition) exceed the MFMA roofline of a direct convolution; `executed_frac` is the MFMA "
-                                  "pipe's own utilisation" if "wino" in ms.kernel_name(dom, opts) else "direct convolution: executed = algorithmic FLOPs"),
+                         "avg_launch_ms": round(dom_ms, 4), "mfma_products_per_fma": products,
+                         "flops_per_launch": dom_flops * products * issued(dom),
+                         "algorithmic_flops_per_launch": dom_flops,
+                         "algorithmic_tflops": round(algorithmic, 3),
+                         "algorithmic_speedup_vs_direct_roofline": round(algorithmic / peak, 4),
+                         "note": ("Winograd F(2x2,3x3) issues 16/36 of the algorithmic multiplies: `achieved` / `frac` are the MFMA pipe's own rate (issued "
+                                  "FLOPs / time / peak); `algorithmic_tflops` is SURVEY 8(d)'s FLOPs over the same time -- above the peak, i.e. faster than a "
+                                  "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs"),
                          "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,
             "output_finite": ok,

@@ -220,4 +220,8 @@ public:
 
 }  // namespace w2xc
 
+// Later upstream releases renamed the namespace (w2xconv::Model, BASELINE.json's north_star uses that name); this snapshot's is
+// w2xc (/root/reference/src/modelHandler.hpp:22, convertRoutine.hpp:20).  Both spellings name the same classes and functions.
+namespace w2xconv = w2xc;
+
 #endif /* W2XC_HIP_MODEL_HANDLER_HPP_ */

@@ -12,7 +12,7 @@
  * "parity unpinned" -- they are restated from OpenCV's documented CPU semantics.
  * What IS pinned: oracle/_ref builds the reference's own modelHandler.cpp and
  * convertRoutine.cpp against a small OpenCV shim (oracle/cvshim), and
- * tests/test_oracle_vs_ref.py demands bit-equality between this restatement and
+ * tests/test_oracle.py demands bit-equality between this restatement and
  * that build (thread partition, weight indexing, JSON loading, pad, block walk,
  * crop, stitch are the reference's own code there).
  *

@@ -33,6 +33,14 @@ static bool write_all(const char *path, const float *p, size_t n)
     return k == n;
 }
 
+#ifdef W2XC_HIP_MODEL_HANDLER_HPP_
+// the adapter also answers to the later upstream namespace name (BASELINE.json's north_star: w2xconv::Model)
+#include <type_traits>
+static_assert(std::is_same<w2xconv::Model, w2xc::Model>::value && std::is_same<w2xconv::modelUtility, w2xc::modelUtility>::value,
+              "namespace w2xconv = w2xc");
+static bool (*const w2xconv_entry)(cv::Mat &, cv::Mat &, std::vector<std::unique_ptr<w2xconv::Model> > &, bool) = &w2xconv::convertWithModels;
+#endif
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;

@@ -133,6 +133,26 @@ def test_in_place_conversion_and_trim(gpu, scale_layers):
     o = gpu.make_opts(band_rows=64)
     assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, C.byref(o)) == 0
     assert np.array_equal(big[:400], want)
+    # in place with MORE THAN ONE unit (W2XC_HOST_BANDS: three units on this device, as three devices would run them): unit t's
+    # output rows are the halo source rows of its neighbours -- the source rows are snapshotted before the units fan out
+    os.environ["W2XC_HOST_BANDS"] = "3"
+    try:
+        assert np.array_equal(ms.convert(x), want)           # (the units stitch to the one-unit result)
+        buf = x.copy()
+        assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, buf.strides[0], 300, 400, buf.ctypes.data, buf.strides[0], 1, None) == 0
+        assert np.array_equal(buf, want), "in place, 3 units"
+        big = np.zeros((405, 300), np.float32)
+        big[5:] = x
+        assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, None) == 0
+        assert np.array_equal(big[:400], want), "overlapping, 3 units"
+        src = x[::2].copy()                                  # nearest-2x entry in place is impossible (sizes differ): overlapping allocation
+        both = np.zeros((500, 300), np.float32)              # source rows 0..99 of the view ARE output rows 300..399
+        both[300:, :150] = src[:, :150]
+        want2 = ms.convert_nn2x(np.ascontiguousarray(src[:, :150]))
+        assert lib.w2xc_convert_plane_nn2x(ms.handle, both[300:].ctypes.data, both.strides[0], 150, 200, both.ctypes.data, both.strides[0], None) == 0
+        assert np.array_equal(both[:400], want2), "nn2x into an overlapping allocation, 3 units"
+    finally:
+        del os.environ["W2XC_HOST_BANDS"]
     ms.trim()
     assert np.array_equal(ms.convert(x), want)
     ms.trim()
@@ -293,9 +313,12 @@ def test_bench_line_single_gpu(gpu):
     for k in ("pageable", "pinned"):
         assert 0 < h[k]["ratio_vs_resident"] < 1.2
     r = j["roofline"]
-    # (`frac` counts ALGORITHMIC FLOPs: with the Winograd kernel on the dominant layer it may pass 1; the pipe's own share is executed_frac)
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 2.25 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
-    assert 0 < r["executed_frac"] < 1 and r["executed_frac"] <= r["frac"] + 1e-9
+    # `achieved` / `frac` = the FLOPs the kernel ISSUES over time (a fraction of the MFMA peak, < 1); the algorithmic rate (SURVEY 8d's
+    # FLOPs over the same time) sits beside it and may pass the peak with a Winograd kernel on the dominant layer
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert r["algorithmic_tflops"] >= r["achieved"] - 1e-6 and abs(r["algorithmic_tflops"] / r["peak"] - r["algorithmic_speedup_vs_direct_roofline"]) < 1e-3
+    assert abs(r["flops_per_launch"] / r["algorithmic_flops_per_launch"] - (16 / 36 if "wino" in r["kernel"] else 1.0)) < 1e-9
+    assert all(0 < l["frac_of_peak"] < 1 for l in j["layers"])
     assert ("conv3x3_wino" in r["kernel"] or "conv3x3_mfma" in r["kernel"]) and "128->128" in r["kernel"]
     assert len(j["layers"]) == 7 and "workload" in j["config"]
 

@@ -41,9 +41,11 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         if k == NL and any(n.startswith("conv3x3_last_gather") for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
-    if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino<CIN, COUT>)
-        sub = "conv3x3_wino<%d, %d>" % (cin, cout)
-        names = [n for n in stats if sub in n]
+    if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino16<CIN, COUT, 0> / conv3x3_wino<CIN, COUT>)
+        for sub in ("conv3x3_wino16<%d, %d," % (cin, cout), "conv3x3_wino<%d, %d>" % (cin, cout)):
+            names = [n for n in stats if sub in n]
+            if names:
+                break
     if not names:
         continue
     name = names[0]
@@ -63,13 +65,14 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     wino = "conv3x3_wino" in name
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": 16.0 / 36.0 if wino else 1.0,
-         "algorithmic_flops": 18 * cin * cout * px, "tflops": 18 * cin * cout * px / avg_ns / 1e3,
+         "algorithmic_flops": 18 * cin * cout * px, "algorithmic_tflops": 18 * cin * cout * px / avg_ns / 1e3,
+         "tflops": 18 * cin * cout * px / avg_ns / 1e3 * (16.0 / 36.0 if wino else 1.0),   # FLOPs the kernel issues / time
          "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
          "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}
     if sub == "conv3x3_last_gather":   # the last layer's MFMA work runs inside layer NL-1's kernel; this kernel only adds 18 floats per pixel
         e["algorithmic_flops"] = 18 * px
-        e["tflops"] = 18 * px / avg_ns / 1e3
+        e["tflops"] = e["algorithmic_tflops"] = 18 * px / avg_ns / 1e3
         e["note"] = "last layer fused into the previous kernel's epilogue; this is the tap/half gather"
     grbm = mean_counter(pmcs[3], sub, "GRBM_GUI_ACTIVE"); busy = mean_counter(pmcs[2], sub, "SQ_VALU_MFMA_BUSY_CYCLES")
     if grbm and busy:
@@ -77,5 +80,5 @@ for k, (cin, cout) in enumerate(PLANES, 1):
                   "avg_waves_per_simd": mean_counter(pmcs[2], sub, "SQ_WAVE_CYCLES") * 4 / (grbm / 8) / 1024,
                   "SQ_LDS_BANK_CONFLICT": mean_counter(pmcs[3], sub, "SQ_LDS_BANK_CONFLICT")})
     out["kernels"][name] = e
-    print(k, name[:44], "%.2f ms %.1f TF  HBM %.2f GB (%.2fx alg)  mfma_util %.3f" % (avg_ns / 1e6, e["tflops"], (rd + wr) / 1e9, e["traffic_over_algorithmic"], e.get("mfma_pipe_utilisation", 0)))
+    print(k, name[:44], "%.2f ms %.1f TF issued  HBM %.2f GB (%.2fx alg)  mfma_util %.3f" % (avg_ns / 1e6, e["tflops"], (rd + wr) / 1e9, e["traffic_over_algorithmic"], e.get("mfma_pipe_utilisation", 0)))
 json.dump(out, open(prefix + "_roofline.json", "w"), indent=1)

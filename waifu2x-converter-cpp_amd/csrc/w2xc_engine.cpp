@@ -286,8 +286,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 // layer 2 is an ordinary split mid layer.  W2XC_SPLIT_FUSE_FIRST=0 disables.
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o)
 {
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("W2XC_SPLIT_FUSE_FIRST"); en = (e && atoi(e) == 0) ? 0 : 1; }
+    static const int en = [] { const char *e = getenv("W2XC_SPLIT_FUSE_FIRST"); return (e && atoi(e) == 0) ? 0 : 1; }();   // (thread-safe initialisation)
     const int n = (int)m->layers.size();
     if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3 || split_terms(o) == 0) return false;
     if (m->layers[0].nin != 1 || m->layers[0].nout != 32) return false;
@@ -299,8 +298,7 @@ bool fuse_first(const w2xc_model *m, const w2xc_opts &o)
 // before it (conv3x3_split, out_terms = 9) and finished by conv3x3_last_gather.  W2XC_SPLIT_FUSE_LAST=0 disables.
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
 {
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("W2XC_SPLIT_FUSE_LAST"); en = (e && atoi(e) == 0) ? 0 : 1; }
+    static const int en = [] { const char *e = getenv("W2XC_SPLIT_FUSE_LAST"); return (e && atoi(e) == 0) ? 0 : 1; }();
     const int n = (int)m->layers.size();
     if (!en || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
     const int T = split_terms(o);
@@ -1019,6 +1017,10 @@ namespace {
 bool host_range_pinned(const void *p, size_t bytes)
 {
     if (!p || bytes == 0) return false;
+    // both ends must be page-locked AND belong to ONE allocation / registration that spans the whole range: two registered
+    // regions with a pageable (or unmapped) gap between them would pass a probe of the end points alone
+    const void *base[2] = {nullptr, nullptr};
+    int i = 0;
     for (const char *q : {(const char *)p, (const char *)p + bytes - 1}) {
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof at);
@@ -1027,8 +1029,19 @@ bool host_range_pinned(const void *p, size_t bytes)
             return false;
         }
         if (at.type != hipMemoryTypeHost) return false;
+        hipDeviceptr_t b = nullptr;
+        size_t sz = 0;
+        if (hipMemGetAddressRange(&b, &sz, (hipDeviceptr_t)at.devicePointer) == hipSuccess && b && sz) {
+            const char *hb = (const char *)at.hostPointer - ((const char *)at.devicePointer - (const char *)b);   // host address of the allocation's start
+            if ((const char *)p < hb || (const char *)p + bytes > hb + sz) return false;
+            base[i] = hb;
+        } else {
+            (void)hipGetLastError();
+            base[i] = nullptr;   // range unknown for this kind of registration: fall back to comparing what we have
+        }
+        i++;
     }
-    return true;
+    return base[0] == base[1];
 }
 
 int pipe_init(HostPipe &p)
@@ -1193,8 +1206,16 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                         drain_err = std::string("hipEventSynchronize(D2H chunk) failed: ") + hipGetErrorString(e);
                         drain_rc.store(W2XC_ERR_HIP);
                     } else {
-                        w2xc_host::CopyPool::get().copy_rows((char *)out + (size_t)ch.r0 * out_stride, out_stride,
-                                                             p.pin_out + (size_t)ch.slot * p.out_slot_bytes, out_row, out_row, ch.r1 - ch.r0, copy_threads);
+                        try {   // (a std::bad_alloc / std::system_error on this thread would be std::terminate, not an error code)
+                            w2xc_host::CopyPool::get().copy_rows((char *)out + (size_t)ch.r0 * out_stride, out_stride,
+                                                                 p.pin_out + (size_t)ch.slot * p.out_slot_bytes, out_row, out_row, ch.r1 - ch.r0, copy_threads);
+                        } catch (const std::exception &ex) {
+                            drain_err = std::string("host copy of a downloaded chunk failed: ") + ex.what();
+                            drain_rc.store(W2XC_ERR_NOMEM);
+                        } catch (...) {
+                            drain_err = "host copy of a downloaded chunk failed";
+                            drain_rc.store(W2XC_ERR_NOMEM);
+                        }
                     }
                 }
                 {
@@ -1333,6 +1354,26 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     }
     const int R = row_end - row_begin;
     if (nd > R) nd = R;
+    // In-place / overlapping planes with MORE THAN ONE unit: unit t writes output rows that are the halo source rows of units t-1 and
+    // t+1 (each unit only protects its own rows, host_rows_on_device), on one device in a deterministic wrong order, on several
+    // devices as a race.  The reference survives convertWithModels(img, img, ...) through its copyMakeBorder temporary
+    // (convertRoutine.cpp:35,96); here the source rows are snapshotted once before the units fan out.
+    std::vector<float> snapshot;
+    if (nd > 1) {
+        const int n = (int)m->layers.size();
+        const int s0 = std::max(0, row_begin - n) >> up, s1 = (std::min(H, row_end + n) + up) >> up;
+        const char *in_lo = (const char *)in + (ptrdiff_t)(s0 - in_row0) * (ptrdiff_t)in_stride_bytes;
+        const char *in_hi = (const char *)in + (ptrdiff_t)(s1 - 1 - in_row0) * (ptrdiff_t)in_stride_bytes + (size_t)w * 4;
+        const char *out_lo = (const char *)out, *out_hi = (const char *)out + (size_t)(R - 1) * out_stride_bytes + (size_t)W * 4;
+        if (in_lo < out_hi && out_lo < in_hi) {
+            snapshot.resize((size_t)(s1 - s0) * w);
+            w2xc_host::CopyPool::get().copy_rows((char *)snapshot.data(), (size_t)w * 4, in_lo, in_stride_bytes, (size_t)w * 4, s1 - s0,
+                                                 std::max(1, std::min(w2xc_get_jobs(), 32)));
+            in = snapshot.data();
+            in_stride_bytes = (size_t)w * 4;
+            in_row0 = s0;
+        }
+    }
     // modelUtility's nJob (modelHandler.hpp:99; the CLI's -j) = host threads that move rows in and out of the staging rings
     const int copy_threads = std::max(1, std::min(w2xc_get_jobs(), 32) / nd);
 
@@ -1343,8 +1384,19 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     auto worker = [&](int t) {
         // contiguous share [ra, rb) of the OUTPUT rows for unit t: independent, no exchange
         const int ra = row_begin + (int)((long long)R * t / nd), rb = row_begin + (int)((long long)R * (t + 1) / nd);
-        rcs[t] = host_rows_on_device(m, devs[t], in, in_stride_bytes, w, h, up, ra, rb, out, out_stride_bytes, o, copy_threads, in_row0, row_begin);
-        if (rcs[t]) errs[t] = g_last_error;
+        try {   // no exception may leave a unit's thread (std::terminate) or cross the C ABI
+            rcs[t] = host_rows_on_device(m, devs[t], in, in_stride_bytes, w, h, up, ra, rb, out, out_stride_bytes, o, copy_threads, in_row0, row_begin);
+            if (rcs[t]) errs[t] = g_last_error;
+        } catch (const std::bad_alloc &) {
+            rcs[t] = W2XC_ERR_NOMEM;
+            errs[t] = "out of host memory in a conversion unit";
+        } catch (const std::exception &ex) {
+            rcs[t] = W2XC_ERR_HIP;
+            errs[t] = std::string("exception in a conversion unit: ") + ex.what();
+        } catch (...) {
+            rcs[t] = W2XC_ERR_HIP;
+            errs[t] = "unknown exception in a conversion unit";
+        }
     };
     if (nd == 1) worker(0);
     else {
