@@ -78,8 +78,12 @@ def test_cfg2_whole_plane_mfma_vs_direct_vs_oracle(gpu, scale_layers):
 
 
 # error against the fp64 truth as a multiple of the CPU oracle's own fp32 error, per fp32 mid-layer kernel (W2XC_KERNEL_* value -> gate);
-# measured in round 3 on the upstream-init / wide-range fixtures, full-range and dark planes: see test_weight_statistics' printout
-FP64_MARGIN = {3: 8.0, 4: 8.0, 2: 8.0}
+# measured in round 3 on the upstream-init / wide-range fixtures, full-range and dark planes (test_weight_statistics prints them):
+#   Winograd (conv3x3_wino16 [+ conv3x3_wino for 32 output planes])  0.85 / 0.87 / 1.04 / 1.36 x   -> gate 3
+#   Winograd32 (conv3x3_wino)                                         0.86 / 0.95 / 1.17 / 0.98 x   -> gate 3
+#   direct MFMA (conv3x3_mfma2, one k-ordered fma chain per output)   1.50 / 1.52 / 1.79 / 4.35 x   -> gate 9
+# i.e. both Winograd kernels sit CLOSER to the fp64 truth than the direct MFMA kernel does (more, shorter partial sums).
+FP64_MARGIN = {3: 3.0, 4: 3.0, 2: 9.0}
 
 
 def test_cfg3_odd_bands_whole_rows_winograd_vs_direct_mfma(gpu, scale_layers):
