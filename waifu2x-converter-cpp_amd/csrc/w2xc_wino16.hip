@@ -45,7 +45,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
 // 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
-// 64 = patch reads but no transform additions; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
+// 64 = patch reads but no transform additions; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
 template <int CIN, int COUT, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
 {
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
         const int ty_ = pt / tiles_x, tx_ = pt - ty_ * tiles_x;
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
         const int yb = clampi(y0, 0, d.in_h - 1), xb = clampi(x0, 0, d.in_w - 1);
-        a_base = reinterpret_cast<const char *>(d.in) + ((long long)yb * d.in_rs + (long long)xb * CIN) * 4;
+        a_base = reinterpret_cast<const char *>(d.in) + ((ABL & 512) ? 0ll : ((long long)yb * d.in_rs + (long long)xb * CIN) * 4);
         const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
         const int rs4 = (int)d.in_rs * 4;   // (a tile spans 10 rows: the byte offsets fit 32 bits for any plane the engine accepts)
 #pragma unroll
@@ -285,26 +285,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                         raw[r * 4 + c] = *reinterpret_cast<const f32x2v *>(pa + r * P_ROW + (c & 1) * P_PAR + (c >> 1) * P_E);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // its transform, two additions per MFMA: columns in slots 22..37, rows in 38..53
-                    if constexpr (slot >= 22 && slot < 38 && !(ABL & (16 | 64))) {
-                        constexpr int o = (slot - 22) * 2;          // op o, o+1 of 32: (c, h, i) = (o >> 3, (o >> 2) & 1, o & 3)
-                        col_op((o >> 2) & 1, o & 3, o >> 3);
-                        col_op(((o + 1) >> 2) & 1, (o + 1) & 3, (o + 1) >> 3);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr (slot >= 38 && slot < 54 && !(ABL & (16 | 64))) {
-                        constexpr int o = (slot - 38) * 2;          // (r, h, j) = (o >> 3, (o >> 2) & 1, o & 3)
-                        row_op(vnext, (o >> 2) & 1, o >> 3, o & 3);
-                        row_op(vnext, ((o + 1) >> 2) & 1, (o + 1) >> 3, (o + 1) & 3);
-                        __builtin_amdgcn_sched_barrier(0);
+                    // its transform: 64 scalar additions in FOUR bunches of 16.  Beside the fp32 MFMA a VALU instruction costs 2 cycles
+                    // of matrix-pipe time (the two share the fp32 lanes) plus ~4.5 cycles for every MFMA gap that holds any VALU at all
+                    // (tools/ubench/mfma_fillers.hip): 4 gaps x 16 beat 32 gaps x 2 by ~6 % of a stage.
+                    if constexpr ((ABL & 256) != 0) {   // (the spread schedule, kept for A/B runs)
+                        if constexpr (slot >= 22 && slot < 38 && !(ABL & (16 | 64))) {
+                            constexpr int o = (slot - 22) * 2;
+                            col_op((o >> 2) & 1, o & 3, o >> 3);
+                            col_op(((o + 1) >> 2) & 1, (o + 1) & 3, (o + 1) >> 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (slot >= 38 && slot < 54 && !(ABL & (16 | 64))) {
+                            constexpr int o = (slot - 38) * 2;
+                            row_op(vnext, (o >> 2) & 1, o >> 3, o & 3);
+                            row_op(vnext, ((o + 1) >> 2) & 1, (o + 1) >> 3, (o + 1) & 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if constexpr (!(ABL & (16 | 64))) {
+                        if constexpr (slot == 22) { transform_cols(0); transform_cols(1); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (slot == 30) { transform_cols(2); transform_cols(3); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (slot == 38) { transform_rows(vnext, 0); transform_rows(vnext, 1); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (slot == 46) { transform_rows(vnext, 2); transform_rows(vnext, 3); __builtin_amdgcn_sched_barrier(0); }
                     }
                     // transfers: U pieces first, tile pieces last (the stage's closing wait leaves the tile pieces in flight)
                     if constexpr (slot == 3 || slot == 7 || slot == 11 || slot == 15) {
                         if constexpr (!(ABL & 1)) dma_b(u_ob, u_sl, uslot ^ 1u, (slot - 3) >> 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (issue_a && (slot == 55 || slot == 57 || slot == 59 || slot == 61)) {
+                    if constexpr (issue_a && !(ABL & 1024) && (slot == 55 || slot == 57 || slot == 59 || slot == 61)) {
                         if constexpr (!(ABL & 2)) dma_a((slot - 55) >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (issue_a && (ABL & 1024) != 0 && (slot == 17 || slot == 19 || slot == 21 || slot == 23)) {
+                        if constexpr (!(ABL & 2)) dma_a((slot - 17) >> 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
@@ -354,11 +367,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                         for (int i = 0; i < 2; i++) {
                             const f32x2v y0 = tm[i][0] + tm[i][1] + tm[i][2] + b2;
                             const f32x2v y1 = tm[i][1] - tm[i][2] - tm[i][3] + b2;
+                            // max(v, 0.1 v) as ONE v_med3_f32(v, 0.1 v, FLT_MAX): fmaxf costs extra canonicalising instructions
                             const f32x2v s0 = y0 * 0.1f, s1 = y1 * 0.1f;
-                            y[i][0][2 * h] = fmaxf(y0[0], s0[0]);
-                            y[i][0][2 * h + 1] = fmaxf(y0[1], s0[1]);
-                            y[i][1][2 * h] = fmaxf(y1[0], s1[0]);
-                            y[i][1][2 * h + 1] = fmaxf(y1[1], s1[1]);
+                            y[i][0][2 * h] = __builtin_amdgcn_fmed3f(y0[0], s0[0], 3.402823466e+38f);
+                            y[i][0][2 * h + 1] = __builtin_amdgcn_fmed3f(y0[1], s0[1], 3.402823466e+38f);
+                            y[i][1][2 * h] = __builtin_amdgcn_fmed3f(y1[0], s1[0], 3.402823466e+38f);
+                            y[i][1][2 * h + 1] = __builtin_amdgcn_fmed3f(y1[1], s1[1], 3.402823466e+38f);
                         }
                     }
                     if constexpr ((ABL & 4) != 0) {
@@ -466,6 +480,11 @@ hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
         case 128: return launch_wino16<128, 128, 128>(d, stream);
         case 135: return launch_wino16<128, 128, 135>(d, stream);
         case 151: return launch_wino16<128, 128, 151>(d, stream);
+        case 256: return launch_wino16<128, 128, 256>(d, stream);
+        case 512: return launch_wino16<128, 128, 512>(d, stream);
+        case 1024: return launch_wino16<128, 128, 1024>(d, stream);
+        case 516: return launch_wino16<128, 128, 516>(d, stream);
+        case 263: return launch_wino16<128, 128, 263>(d, stream);
         default: break;
     }
 #endif
