@@ -10,8 +10,9 @@
 //                  transfers, the whole epilogue) is time the matrix pipe of that SIMD idles: measured 0.55-0.72 of the MFMA peak.
 //   conv3x3_wino16 16x16x4 MFMA (same rate, 32 cycles): a wave owns 32 planes x 16 blocks x 16 xi = 128 accumulators, so TWO waves
 //                  fit a SIMD.  The workgroup is 8 waves = 2 PLANE GROUPS x 4 block rows: both groups work on the same pixel tile
-//                  (one tile transfer serves 64 output planes) and group 1 runs ONE STAGE BEHIND group 0, so that a group's
-//                  epilogue and stage head run under the other group's MFMAs instead of beside its epilogue.
+//                  (one tile transfer serves 64 output planes), in the same stage.  (A variant with group 1 one stage behind group 0 --
+//                  so that one group's epilogue runs under the other's MFMAs -- measured the same and was dropped: the fp32 MFMA
+//                  and the VALU share the fp32 lanes, an epilogue costs its ALU cycles wherever it runs.)
 //
 //   Work item  8 rows x 32 pixels of output (4 x 16 blocks) x 64 output planes; wave (g, w): plane group g, block row w.
 //              Lane (t = lane & 15, k = lane >> 4): block t of the row; K index k of the MFMA = channels 2k, 2k+1 of a slice.
@@ -28,8 +29,8 @@
 //              U[2 groups][2] x 16 KiB: the weights of (plane block, slice) in fragment order [step][plane tile][xi/4][lane][xi%4].
 //              + 8 KiB per-lane transfer offsets + 1 KiB dump + bias: 155 KiB, one workgroup per CU.
 //   Transfers  SGPR base + 32-bit lane offset; per wave and stage 4 U pieces (own group, one stage ahead), and every second stage 4 tile
-//              pieces (two 16-channel slices ahead, both groups in the same global stage); U first, tile pieces last, so the stage's
-//              closing COUNTED vmcnt leaves the tile pieces in flight.
+//              pieces (two 16-channel slices ahead); U first, tile pieces last, so the stage's closing COUNTED vmcnt leaves the
+//              tile pieces in flight.
 //   Epilogue   output transform, bias, LeakyReLU, 16-byte NHWC stores (a lane holds 4 consecutive planes of its block's 4 pixels).
 //   Banding    blocks sit on EVEN rows of the layer's whole output (W2xcConvDesc::wino_py), as in conv3x3_wino.
 #include "w2xc_kernels.h"
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
     const int t = lane & 15, k = lane >> 4;
 
     // persistent schedule: XCD x (= blockIdx % 8) walks its own contiguous chunk of the item list; this workgroup's items are
-    // item_of(0), item_of(1), ... (both plane groups walk the same list, group 1 one stage behind)
+    // item_of(0), item_of(1), ...
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const int cq = nitems >> 3, cr = nitems & 7;
     const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
@@ -128,8 +129,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
             voff[jj] = (unsigned)(gy * rs4 + (gx * CIN + 4 * ch) * 4);
         }
     };
-    // tile-transfer cursor: the next 16-channel slice to fetch is slice a_lp of item_of(a_n), into tile buffer a_buf (0, 1, 2, 0, ...).
-    // Both plane groups advance it in the same global stage.
+    // tile-transfer cursor: the next 16-channel slice to fetch is slice a_lp of item_of(a_n), into tile buffer a_buf (0, 1, 2, 0, ...)
     int a_n = 0, a_lp = 0;
     unsigned a_buf = 0;
     auto dma_a = [&](int jj) {
@@ -213,12 +213,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // The rest runs once per plane group, with the group as a compile-time constant: the groups differ in WHICH stages carry
-    // the tile transfers (the same global stage = even stages of group 0, odd ones of group 1), and a run-time branch inside
-    // a stage costs a wait-everything at every join.
-    auto run = [&](auto GRP) {
-        constexpr int G = decltype(GRP)::value;
-        // V of stage 0 (group 1: under group 0's stage 0, with the tile transfers of that global stage)
+    {
+        // V of the first stage
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -228,14 +224,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
         for (int c = 0; c < 4; c++) transform_cols(c);
 #pragma unroll
         for (int r = 0; r < 4; r++) transform_rows(va, r);
-        if constexpr (G == 1) {
-#pragma unroll
-            for (int jj = 0; jj < APW; jj++) dma_a(jj);
-            a_advance();
-            W2XC_WAIT_VMCNT(APW);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
 
         unsigned cbuf = 0;     // tile buffer of the CURRENT stage's 16-channel slice
         unsigned uslot = 0;
@@ -246,10 +234,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
             auto stage = [&](auto FIRST, auto ODD, int sl, VSet &vcur, VSet &vnext) {
                 constexpr bool first = decltype(FIRST)::value;
                 constexpr int odd = decltype(ODD)::value;               // sl & 1 (NSL is even: also the parity of the global stage count)
-                constexpr bool issue_a = (odd == G);                    // this stage carries tile transfers
+                constexpr bool issue_a = (odd == 0);                    // even stages carry the tile transfers
                 // transfers of this stage: U of the next stage (own group)
-                int u_ob = (item % NOB) * 2 + G, u_sl = sl + 1;
-                if (sl == NSL - 1) { u_ob = (item_n % NOB) * 2 + G; u_sl = 0; }
+                int u_ob = (item % NOB) * 2 + grp, u_sl = sl + 1;
+                if (sl == NSL - 1) { u_ob = (item_n % NOB) * 2 + grp; u_sl = 0; }
                 // the next stage's patch: even stage -> second half of the current 16-channel slice; odd stage -> first half of the next one
                 const unsigned rbuf = odd ? (cbuf == 2 ? 0u : cbuf + 1u) : cbuf;
                 const char *pa = ldsb + rbuf * A_BYTES + pbase + (odd ? 0 : 32);
@@ -342,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                 if constexpr ((ABL & 128) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
                 // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
                 //      C/D of the 16x16 MFMA: lane & 15 = block, register e = plane 4 * (lane >> 4) + e of the plane tile ----
-                const int ob = (item % NOB) * 2 + G, ptile = item / NOB;
+                const int ob = (item % NOB) * 2 + grp, ptile = item / NOB;
                 const int tile_y = ptile / tiles_x, tile_x = ptile - tile_y * tiles_x;
                 const int ty0 = tile_y * ROWS - d.wino_py;
                 const int oy = ty0 + 2 * brow, ox = tile_x * 32 + 2 * t;
@@ -393,13 +381,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                 }
             }
         }
-        if constexpr (G == 0) {   // group 1's last stage
-            W2XC_WAIT_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-        }
-    };
-    if (grp == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
+    }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
 }
 
