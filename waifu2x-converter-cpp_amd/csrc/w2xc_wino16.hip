@@ -44,6 +44,15 @@
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+#ifdef W16_TIMING
+// tools/ubench/wino16_timing.hip: s_memtime stamps of block row 0 of each plane group of workgroup 0 -- per stage (before the closing
+// wait, after it, after the barrier) and after every epilogue -- [group][index].  (The stamps are stores: they perturb what they measure.)
+__device__ unsigned long long w16_stamps[2][4096];
+#define W16_STAMP(idx) do { const int i_ = (idx); if (blockIdx.x == 0 && brow == 0 && lane == 0 && i_ < 4096) w16_stamps[grp][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W16_STAMP(idx) do { } while (0)
+#endif
+
 // ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
 // 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
 // 64 = patch reads but no transform additions; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
@@ -227,6 +236,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
 
         unsigned cbuf = 0;     // tile buffer of the CURRENT stage's 16-channel slice
         unsigned uslot = 0;
+        int stamp = 0;
+        (void)stamp;
+        W16_STAMP(stamp++);
         for (int n = 0; n < nmy; n++) {
             const int item = item_of(n), item_n = item_of(n + 1);
             // The accumulators are DEFINED by the first stage of an item (C = 0) and die in its epilogue
@@ -310,13 +322,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                     }
                 });
                 if constexpr (issue_a) a_advance();
+                W16_STAMP(stamp++);
                 // U(next stage) and every older tile piece have landed; this stage's tile pieces (the youngest) may still fly
                 if constexpr (issue_a && !(ABL & 2)) W2XC_WAIT_VMCNT(APW);
                 else W2XC_WAIT_VMCNT(0);
+                W16_STAMP(stamp++);
                 if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if constexpr (odd) cbuf = rbuf;
                 uslot ^= 1u;
+                W16_STAMP(stamp++);
             };
             stage(std::true_type{}, std::integral_constant<int, 0>{}, 0, va, vb);
 #pragma unroll 1
@@ -379,6 +394,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                                     *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
                     }
                 }
+                W16_STAMP(stamp++);
             }
         }
     }
