@@ -55,7 +55,7 @@ __device__ unsigned long long w16_stamps[2][4096];
 
 // ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
 // 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
-// 64 = patch reads but no transform additions; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
+// 64 = patch reads but no transform additions; 2048 = epilogue at normal priority; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
 template <int CIN, int COUT, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
 {
@@ -341,6 +341,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
             }
             stage(std::false_type{}, std::integral_constant<int, 1>{}, NSL - 1, vb, va);
             {
+                // The epilogue at RAISED priority: the two waves of a SIMD leave their last stage together, the older one wins every issue
+                // slot, finishes its epilogue first and starts the next item's MFMAs -- under which the younger wave's epilogue then
+                // trickles out (s_memtime: 2600 vs 6100 cycles) while the older one ends up waiting at the next barrier.
+                if constexpr (!(ABL & 2048)) __builtin_amdgcn_s_setprio(2);
                 // (the hazard recogniser does not see inside inline asm: let the last MFMAs drain before VALU reads their results)
                 if constexpr ((ABL & 128) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
                 // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
@@ -394,6 +398,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                                     *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
                     }
                 }
+                if constexpr (!(ABL & 2048)) __builtin_amdgcn_s_setprio(0);
                 W16_STAMP(stamp++);
             }
         }
@@ -479,6 +484,7 @@ hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
         case 135: return launch_wino16<128, 128, 135>(d, stream);
         case 151: return launch_wino16<128, 128, 151>(d, stream);
         case 256: return launch_wino16<128, 128, 256>(d, stream);
+        case 2048: return launch_wino16<128, 128, 2048>(d, stream);
         case 512: return launch_wino16<128, 128, 512>(d, stream);
         case 1024: return launch_wino16<128, 128, 1024>(d, stream);
         case 516: return launch_wino16<128, 128, 516>(d, stream);
