@@ -461,6 +461,9 @@ def main():
                               # SURVEY 8(d)'s algorithmic FLOPs over the same time
                               "algorithmic_tflops": round(alg_tf, 2) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
+            if per_layer[-1]["kernel"] == "conv3x3_last_gather":
+                per_layer[-1]["note"] = ("last layer fused: its MFMA work runs in the previous layer's epilogue (that layer's `ms` includes it, its FLOP "
+                                         "figures do not); this launch only sums the partial tap planes")
         traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
                                  if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else (None, "no PMC profile for this configuration"))
         wl_name = {"scale2x_1080p": "scale2x_1080p (BASELINE.json configs[1])", "plane": "plane, row-sharded over ranks (BASELINE.json configs[2] at 8192x8192)",

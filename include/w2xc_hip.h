@@ -80,7 +80,15 @@ typedef struct w2xc_opts {
                                * promises they are unmodified, and the copy still on the device is used instead of
                                * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
                                * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
+    int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path (the one-plane last layer inside the epilogue
+                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  Results stay
+                               * inside the fp32 gate either way (tests/test_gpu_winograd.py); W2XC_FUSION_AUTO = on unless the
+                               * environment says W2XC_FUSE_LAST_FP32=0.  (The 16-bit modes: W2XC_SPLIT_FUSE_FIRST / _LAST.) */
 } w2xc_opts;
+
+#define W2XC_FUSION_AUTO 0
+#define W2XC_FUSION_OFF  1
+#define W2XC_FUSION_ON   2
 
 /* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding). */
 void w2xc_opts_init(w2xc_opts *o);

@@ -160,7 +160,7 @@ def test_opts_struct_size_versions_the_abi(w2xc, noise1_layers):
     new.future_a = -1
     assert name(ms.handle, 0, C.cast(C.byref(new), C.POINTER(w2xc.Opts))) == b"conv3x3_direct"
     o = w2xc.make_opts()
-    assert o.filter_resident == 0 and o.struct_size == C.sizeof(w2xc.Opts) == 40
+    assert o.filter_resident == 0 and o.fusion == w2xc.FUSION_AUTO and o.struct_size == C.sizeof(w2xc.Opts) == 44
 
 
 def test_hostile_model_files_do_not_cross_the_abi(w2xc, tmp_path):
@@ -190,7 +190,13 @@ def test_argument_validation(w2xc, noise1_layers):
     with pytest.raises(w2xc.W2xcError) as e:
         ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
     assert e.value.code == w2xc.ERR_PLANES
-    assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first" and ms.kernel_name(6) == "conv3x3_last"
+    assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first"
+    # the one-plane last layer: inside conv3x3_wino16's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
+    fused = MID_128 == "conv3x3_wino16" and os.environ.get("W2XC_FUSE_LAST_FP32", "1") != "0"
+    assert ms.kernel_name(6) == ("conv3x3_last_gather" if fused else "conv3x3_last")
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_last"
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last_gather"
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_MFMA)) == "conv3x3_last"   # (no fused epilogue in that kernel)
     assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino16 leaves 32 OUTPUT planes to conv3x3_wino)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma"          # per-call choice of the mid-layer kernel
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_wino16"

@@ -88,3 +88,34 @@ def test_winograd_vs_oracle(gpu, planes, name):
     got, want = ms.convert(x, opts=_opts(gpu, name)), orc.Oracle(layers).convert(x)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("planes", [[1, 32, 32, 64, 64, 128, 128, 1], [1, 32, 64, 1], [1, 64, 128, 64, 1], [1, 32, 128, 1]])
+def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
+    """N3 on the fp32 path: the one-plane last layer inside conv3x3_wino16's epilogue (taps-as-rows MFMAs on the activations the epilogue
+    has just produced; Cout / 32 x 9 partial tap planes + conv3x3_last_gather) against the separate conv3x3_last launch
+    (w2xc_opts.fusion = W2XC_FUSION_ON / _OFF) and against the CPU oracle.  Same fp32 arithmetic type, the last layer's channel sum
+    split in 32-plane partials: the two runs agree to the level two fp32 summation orders do.  Odd sizes, planes smaller than a
+    work item, banding (bit-identical inside the fused run), the nearest-2x entry and the host pipeline's chunked path (>= 128 rows)."""
+    from oracle import oracle as orc
+    from tools import gen_model
+    layers = gen_model.synth_layers(planes, 77 + len(planes))
+    ms = gpu._ModelSet.from_layers(layers)
+    n = len(planes) - 1
+    on, off = gpu.make_opts(fusion=gpu.FUSION_ON), gpu.make_opts(fusion=gpu.FUSION_OFF)
+    assert ms.kernel_name(n - 1, on) == "conv3x3_last_gather" and ms.kernel_name(n - 2, on) == "conv3x3_wino16"
+    assert ms.kernel_name(n - 1, off) == "conv3x3_last"
+    o = orc.Oracle(layers)
+    worst = 0.0
+    for (h, wd) in ((37, 61), (8, 32), (300, 170), (1, 1), (16, 33)):
+        x = np.random.default_rng(h * 11 + wd).random((h, wd), dtype=np.float32)
+        a, b = ms.convert(x, opts=on), ms.convert(x, opts=off)
+        worst = max(worst, float(np.abs(a - b).max() / np.abs(b).max()))
+        for band in (1, 7, 64):
+            assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(fusion=gpu.FUSION_ON, band_rows=band))), ("banding", planes, h, wd, band)
+        want = o.convert(x, njob=8)
+        assert np.allclose(a, want, rtol=1e-4, atol=1e-5) and np.abs(a - want).max() <= 1e-5 * np.abs(want).max()
+        a2, b2 = ms.convert_nn2x(x, opts=on), ms.convert_nn2x(x, opts=off)
+        worst = max(worst, float(np.abs(a2 - b2).max() / np.abs(b2).max()))
+    print("fused vs unfused last layer, %s: max err %.2e of the output range" % (planes, worst))
+    assert worst <= 4e-6, worst

@@ -30,6 +30,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libw2xc_hip.so")
 OK, ERR_IO, ERR_JSON, ERR_ARG, ERR_PLANES, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 PRECISION_FP32, PRECISION_BF16, PRECISION_BF16X2, PRECISION_BF16X3, PRECISION_FP16X2 = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MFMA, KERNEL_WINOGRAD, KERNEL_WINOGRAD32 = 0, 1, 2, 3, 4
+FUSION_AUTO, FUSION_OFF, FUSION_ON = 0, 1, 2
 
 
 class W2xcError(RuntimeError):
@@ -42,7 +43,7 @@ class Opts(C.Structure):
     """struct w2xc_opts (include/w2xc_hip.h)."""
     _fields_ = [("struct_size", C.c_int), ("precision", C.c_int), ("kernel", C.c_int), ("device", C.c_int),
                 ("device_mask", C.c_uint), ("band_rows", C.c_int), ("workspace_mb", C.c_int),
-                ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int)]
+                ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int), ("fusion", C.c_int)]
 
 
 def _load():

@@ -84,6 +84,7 @@ struct DevLayer {
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
     float last_fused_scale[4] = {1, 1, 1, 1};
+    float *w_last_wino16 = nullptr;   // w2xc_wino16_pack_last image (fp32 path: last layer inside conv3x3_wino16's epilogue)
     float *bias = nullptr;
 };
 
@@ -174,6 +175,7 @@ struct DevCtx {
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_wino) hipFree(l.w_wino);
             if (l.w_wino16) hipFree(l.w_wino16);
+            if (l.w_last_wino16) hipFree(l.w_last_wino16);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
             for (float *p : l.w_last_fused)
@@ -263,6 +265,7 @@ int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 
 
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
+bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o);
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
@@ -279,6 +282,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
         if (k == W2XC_K_LAST && l == n - 1 && l > 0) return fuse_last(m, o) ? W2XC_K_LAST_GATHER : W2XC_K_LAST;
         return W2XC_K_DIRECT;   // run_rows rejects this
     }
+    if (k == W2XC_K_LAST && l == n - 1 && fuse_last_fp32(m, o)) return W2XC_K_LAST_GATHER;
     return k;
 }
 
@@ -307,14 +311,19 @@ bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
            w2xc_pick_kernel(m->layers[n - 2].nin, m->layers[n - 2].nout) == W2XC_K_MFMA && n - 2 > 0;
 }
 
-// terms of layer l's OUTPUT in the split pipeline: T when layer l+1 is a split mid layer, else 0 (fp32)
+// terms of layer l's OUTPUT in the split pipeline: T when layer l+1 is a split mid layer, else 0 (fp32); 9 = this layer writes
+// the partial tap planes of the last layer it computes in its epilogue (16-bit modes: conv3x3_split; fp32: conv3x3_wino16)
 int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     const int T = split_terms(o), n = (int)m->layers.size();
-    if (T == 0 || l + 1 >= n) return 0;
+    if (T == 0) return (l == n - 2 && fuse_last_fp32(m, o)) ? 9 : 0;
+    if (l + 1 >= n) return 0;
     if (l == n - 2 && fuse_last(m, o)) return 9;
     return layer_kind(m, l + 1, o) == W2XC_K_MID_SPLIT ? T : 0;
 }
+
+// partial-G planes a fused-last producer writes per tap: wave columns of the split tile shapes, 32-plane blocks of conv3x3_wino16
+int fused_halves(int T, int cout) { return T > 0 ? w2xc_split_halves(T, cout) : cout / 32; }
 
 int upload(const std::vector<float> &h, float **d)
 {
@@ -420,6 +429,20 @@ int mid_variant_for(int midv, int cin, int cout)
     return midv;
 }
 
+// fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
+// the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
+// w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
+bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
+{
+    static const int env_default = [] { const char *e = getenv("W2XC_FUSE_LAST_FP32"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    const int n = (int)m->layers.size();
+    if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
+    if (o.fusion == W2XC_FUSION_OFF || (o.fusion != W2XC_FUSION_ON && !env_default)) return false;
+    const HostLayer &p = m->layers[n - 2], &q = m->layers[n - 1];
+    if (q.nout != 1 || q.nin != p.nout || w2xc_pick_kernel(q.nin, 1) != W2XC_K_LAST || w2xc_pick_kernel(p.nin, p.nout) != W2XC_K_MFMA) return false;
+    return mid_variant_for(mid_variant(o), p.nin, p.nout) == MID_WINO16;
+}
+
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
 {
     DevLayer &dl = c->layers[l];
@@ -471,6 +494,16 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
             if (rc) return rc;
         }
         d.wpk = img;
+        if (d.out_terms == 9) {   // the next (last) layer's weights ride along (fuse_last_fp32)
+            DevLayer &nl = c->layers[l + 1];
+            if (!nl.w_last_wino16) {
+                std::vector<float> pk(w2xc_wino16_pack_last_floats(m->layers[l + 1].nin));
+                w2xc_wino16_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
+                int rc = upload(pk, &nl.w_last_wino16);
+                if (rc) return rc;
+            }
+            d.w7pk = nl.w_last_wino16;
+        }
     }
     d.bias = dl.bias;
     ProfEvent ev;
@@ -548,8 +581,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (k == n && last_direct) break;   // written straight to d_out
             if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
             const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
-            const bool fused = T > 0 && out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
-            const size_t px_bytes = fused ? (size_t)w2xc_split_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
+            const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
+            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * px_bytes);
         }
     };
@@ -626,6 +659,10 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 d.off_y = first_d.off_y; d.off_x = first_d.off_x; d.in_shift = first_d.in_shift;
             }
             int split_grp = 0;
+            if (T == 0) {   // fp32: only the fused last layer uses the term fields
+                d.out_terms = out_terms_of(m, k - 1, o);
+                if (kind == W2XC_K_LAST_GATHER) { d.halves = src_halves; d.in_ts = src_ts; d.in_gs = src_gs; }
+            }
             if (T > 0) {
                 d.terms = (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) ? T : 0;
                 if (kind == W2XC_K_LAST_GATHER) d.halves = src_halves;
@@ -645,18 +682,18 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
                 if (T > 0 && d.out_terms >= 1 && d.out_terms <= 3) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
-                if (T > 0 && d.out_terms == 9) {   // G[half][tap][y][x]
+                if (d.out_terms == 9) {   // G[half][tap][y][x]
                     d.out_rs = d.out_w; d.out_ps = 1;
                     d.out_gs = (long long)d.out_h * d.out_w;
                     d.out_ts = 9 * d.out_gs;
-                    d.halves = w2xc_split_halves(T, hl.nout);
+                    d.halves = fused_halves(T, hl.nout);
                 }
             }
             // 16-bit modes, host pipeline: the last layer lives in layer n-1's epilogue + a 0.2 ms gather, too short to hide the
             // band's download behind.  So layer n-1 and the gather run TOGETHER in row chunks (quarters of the band, whole 16-row
             // tiles): chunk j's rows leave for the host under layer n-1 of chunk j+1.  The producer chunks tile the G rows without
             // overlap (chunk j computes G rows up to r1 + 2, the next one continues there): no recompute.
-            if (hk && T > 0 && k == n - 1 && n >= 3 && kind == W2XC_K_MID_SPLIT && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
+            if (hk && k == n - 1 && n >= 3 && (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_MFMA) && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
                 hk->output_ready && (y1 - y0) >= 128) {
                 if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
                 const int R = y1 - y0;
@@ -1505,11 +1542,15 @@ bool nhwc_ok(const float *p, long long cs, long long rs, long long ps, int plane
 // kernels want NHWC (cs = 1, ps = planes); other layouts are repacked through the context's NHWC buffers
 // nhwc[ob ^ 1] (input) / nhwc[ob] (output).  *res_nhwc tells whether an NHWC copy of the result was left in nhwc[ob].
 int filter_on_device(w2xc_model *m, DevCtx *c, int layer, const float *in, long long in_cs, long long in_rs, long long in_ps, int w, int h,
-                     float *out, long long out_cs, long long out_rs, long long out_ps, hipStream_t st, const w2xc_opts &o, int ob, bool *res_nhwc)
+                     float *out, long long out_cs, long long out_rs, long long out_ps, hipStream_t st, const w2xc_opts &o_, int ob, bool *res_nhwc)
 {
     const HostLayer &hl = m->layers[layer];
     FilterCache &fc = c->fc;
     const size_t px = (size_t)w * h;
+    w2xc_opts of = o_;          // Model::filter runs ONE layer: nothing to fuse it with (and no profiling events)
+    of.fusion = W2XC_FUSION_OFF;
+    of.profile = 0;
+    const w2xc_opts &o = of;
     const W2xcKernelKind kind = layer_kind(m, layer, o);
     const bool want_nhwc_in = (kind == W2XC_K_MFMA || kind == W2XC_K_LAST);
     const bool writes_nhwc = (kind == W2XC_K_MFMA || kind == W2XC_K_FIRST);
@@ -1534,8 +1575,6 @@ int filter_on_device(w2xc_model *m, DevCtx *c, int layer, const float *in, long 
         if (rc) return rc;
         d.out = fc.nhwc[ob]; d.out_rs = (long long)w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
     }
-    w2xc_opts of = o;
-    of.profile = 0;
     int r = launch_layer(c, m, layer, kind, d, st, of);
     if (r) return r;
     if (!direct_out) HIP_TRY(w2xc_launch_repack(d.out, d.out_rs, d.out_ps, 1, out, out_rs, out_ps, out_cs, h, w, hl.nout, st));

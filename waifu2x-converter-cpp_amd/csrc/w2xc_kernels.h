@@ -83,6 +83,10 @@ hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
 bool w2xc_wino16_supported(int cin, int cout);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
+// d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,
+// `out` = partial tap planes G[32-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 32
+size_t w2xc_wino16_pack_last_floats(int cin);
+void w2xc_wino16_pack_last(int cin, const float *w, float *dst);
 
 // split kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` 16-bit terms of every weight in
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.

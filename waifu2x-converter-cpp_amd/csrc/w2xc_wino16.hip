@@ -56,7 +56,11 @@ __device__ unsigned long long w16_stamps[2][4096];
 // ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
 // 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
 // 64 = patch reads but no transform additions; 2048 = epilogue at normal priority; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
-template <int CIN, int COUT, int ABL = 0>
+// FUSE: the NEXT layer is the model's last one with ONE output plane (every waifu2x model): it is computed in this kernel's epilogue
+// ("taps as rows": G[tap][pixel] = sum_c W_last[c][tap] act[c][pixel], 32 more MFMAs per item and wave, on the activations the epilogue
+// has just produced) and `out` receives the partial tap planes G[32-plane block][tap][y][x] (d.out_ts / out_gs / out_rs) that
+// conv3x3_last_gather sums -- 144 instead of 512 bytes per pixel written, and the 512 the last layer would read never exist.
+template <int CIN, int COUT, int ABL = 0, bool FUSE = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
 {
     constexpr int ROWS = 8, HW = 34, HH = ROWS + 2;
@@ -355,6 +359,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                 const int oy = ty0 + 2 * brow, ox = tile_x * 32 + 2 * t;
                 float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * k;
                 const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
+                // FUSE: the last layer's weights for this wave's 32 planes as MFMA A operands, w7[pt * 4 + e] = W_last[plane 32 ob + 16 pt +
+                // 4 k + e][tap = lane & 15] (0 for taps >= 9): 32 bytes per lane, L2-resident
+                f32x4 w7lo = {0.0f, 0.0f, 0.0f, 0.0f}, w7hi = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 gacc[2][2];
+                if constexpr (FUSE) {
+                    const f32x4 *w7 = reinterpret_cast<const f32x4 *>(d.w7pk) + ((size_t)ob * 64 + lane) * 2;
+                    w7lo = w7[0];
+                    w7hi = w7[1];
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) gacc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++) {
                     const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + (ob * 32 + 16 * pt + 4 * k) * 4);
@@ -382,7 +399,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                             y[i][1][2 * h + 1] = __builtin_amdgcn_fmed3f(y1[1], s1[1], 3.402823466e+38f);
                         }
                     }
-                    if constexpr ((ABL & 4) != 0) {
+                    if constexpr (FUSE) {
+                        // G[tap][block] += W_last[tap][channel 4 k + e] * act[channel 4 k + e][block], one MFMA per e: the D layout of the
+                        // activations (lane quarter k holds planes 4 k .. 4 k + 3) is the B operand of K-step e as it stands
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++)
+                                    gacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pt == 0 ? w7lo[e] : w7hi[e], y[i][j][e], gacc[i][j], 0, 0, 0);
+                    } else if constexpr ((ABL & 4) != 0) {
                         if (y[0][0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0][0] + y[0][1] + y[1][0] + y[1][1];
                     } else if (interior) {
 #pragma unroll
@@ -396,6 +423,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                             for (int j = 0; j < 2; j++)
                                 if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w)
                                     *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT + 16 * pt) = y[i][j];
+                    }
+                }
+                if constexpr (FUSE) {
+                    // D layout of G: lane & 15 = block, register e = tap 4 k + e (k = 0, 1: four taps; k = 2: tap 8; k = 3: none)
+                    float *gbase = d.out + (long long)ob * d.out_ts + (long long)(4 * k) * d.out_gs + (long long)oy * d.out_rs + ox;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (4 * k + e < 9) {
+#pragma unroll
+                            for (int i = 0; i < 2; i++)
+#pragma unroll
+                                for (int j = 0; j < 2; j++)
+                                    if (interior || (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w))
+                                        gbase[(long long)e * d.out_gs + (long long)i * d.out_rs + j] = gacc[i][j][e];
+                        }
                     }
                 }
                 if constexpr (!(ABL & 2048)) __builtin_amdgcn_s_setprio(0);
@@ -438,14 +480,28 @@ void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst)
                     }
 }
 
-template <int CIN, int COUT, int ABL = 0>
+// The last layer's weights for the FUSE epilogue: dst[32-plane block ob][lane][pt * 4 + e] = w[plane 32 ob + 16 pt + 4 (lane >> 4) + e][tap lane & 15]
+// (0 for taps >= 9); w is the one-plane last layer's [1][cin][3][3] (modelHandler.cpp:102).  16 * cin floats.
+size_t w2xc_wino16_pack_last_floats(int cin) { return (size_t)16 * cin; }
+void w2xc_wino16_pack_last(int cin, const float *w, float *dst)
+{
+    for (int ob = 0; ob < cin / 32; ob++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int pt = 0; pt < 2; pt++)
+                for (int e = 0; e < 4; e++) {
+                    const int plane = 32 * ob + 16 * pt + 4 * (lane >> 4) + e, tap = lane & 15;
+                    dst[((size_t)ob * 64 + lane) * 8 + pt * 4 + e] = tap < 9 ? w[(size_t)plane * 9 + tap] : 0.0f;
+                }
+}
+
+template <int CIN, int COUT, int ABL = 0, bool FUSE = false>
 static hipError_t launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 1) + 7) / 8;
     const int nitems = tiles_x * tiles_y * (COUT / 64);
     constexpr size_t lds_bytes = 3 * (size_t)(27 * 1024) + 1024 + 4 * (size_t)(16 * 1024) + 4 * 512 * 4 + COUT * 4;   // tile ring + dump + U rings + offset table + bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_wino16<CIN, COUT, ABL>;
+    auto kern = conv3x3_wino16<CIN, COUT, ABL, FUSE>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -465,7 +521,20 @@ static hipError_t launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1 || d.in_shift != 0) return hipErrorInvalidValue;
+    if (d.in_ps != d.cin || d.in_cs != 1 || d.in_shift != 0) return hipErrorInvalidValue;
+    if (d.out_terms != 9 && (d.out_ps != d.cout || d.out_cs != 1)) return hipErrorInvalidValue;
+    if (d.out_terms == 9) {   // last layer fused: `out` = partial tap planes, d.w7pk = w2xc_wino16_pack_last image
+        if (!d.w7pk || (d.in_rs & 3) != 0) return hipErrorInvalidValue;
+        switch (d.cin * 1000 + d.cout) {
+        case 32064:  return launch_wino16<32, 64, 0, true>(d, stream);
+        case 32128:  return launch_wino16<32, 128, 0, true>(d, stream);
+        case 64064:  return launch_wino16<64, 64, 0, true>(d, stream);
+        case 64128:  return launch_wino16<64, 128, 0, true>(d, stream);
+        case 128064: return launch_wino16<128, 64, 0, true>(d, stream);
+        case 128128: return launch_wino16<128, 128, 0, true>(d, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if ((d.in_rs & 3) != 0 || (d.out_rs & 3) != 0) return hipErrorInvalidValue;   // 16-byte accesses
 #ifdef W16_ABLATE
     static const int abl = [] { const char *e = getenv("W2XC_W16_ABL"); return e ? atoi(e) : 0; }();
