@@ -244,6 +244,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def per_rank(x):
+        """every rank's value of x, on rank 0's line (a SCALE record then checks itself: N entries, the MAX is the one used)"""
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(v.item()) for v in out]
+
     def time_steps(step, steps, warmup):
         """the bench contract: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks"""
         for _ in range(warmup):
@@ -296,6 +305,8 @@ def main():
         step, step_prof, d_in, d_out = resident_frame(y_src, lambda p: mk_opts(p))
 
     elapsed = time_steps(step, args.steps, args.warmup)
+    # (a second, un-reduced look at the same K steps per rank would perturb the timed region: the per-rank figure is this rank's own
+    #  wall time of the profiled pass below)
     # second pass, same K steps, with the per-layer hipEvents on the launch stream: per-kernel durations for `roofline`
     ms.profile_reset(dev_index)
     sync_all()
@@ -303,7 +314,10 @@ def main():
     for _ in range(args.steps):
         step_prof()
     sync_all()
-    elapsed_prof = max_over_ranks(time.perf_counter() - tp0)
+    elapsed_prof_own = time.perf_counter() - tp0
+    elapsed_prof = max_over_ranks(elapsed_prof_own)
+    rank_ms = per_rank(elapsed_prof_own / args.steps * 1e3)
+    rank_dev = per_rank(float(torch.cuda.current_device()))
     layer_ms, launches = ms.profile_read(dev_index)
     ok = bool(torch.isfinite(d_out.float()).all().item())
     if args.dump_out:
@@ -492,6 +506,11 @@ def main():
                        "sharding": ("contiguous row ranges of one plane per rank, no collective on the data path, host-side gather" if sharded
                                     else "independent frames per rank, no collective on the data path")},
             "ms_per_step_profiled": round(elapsed_prof / args.steps * 1e3, 4),
+            # self-check of a multi-rank record: the world size the process group reports, the devices the ranks sit on, and each
+            # rank's own ms per step (profiled pass, barrier to barrier): N entries, all close to `ms_per_step`, or the run is not N-wide
+            "ranks_seen": (dist.get_world_size() if dist is not None else 1), "backend": backend if dist is not None else None,
+            "visible_devices": torch.cuda.device_count(), "rank_devices": [int(v) for v in rank_dev],
+            "rank_ms_per_step": [round(v, 4) for v in rank_ms],
             "roofline": {"bound": "mfma", "kernel": "%s (layer %d, %d->%d)" % ((ms.kernel_name(dom, opts), dom + 1) + ms.planes(dom)),
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),

@@ -9,6 +9,8 @@ C ABI, against the oracle.
   configs[4]  3->128->...->3 on three 2048x2048 planes
 plus the weight statistics the synthetic He-init models do not have: the init the real models were trained from
 (srcnn.lua:5-9) and a trained-model-like 10^3 dynamic range with exact zeros, through fp32 AND FP16X2."""
+import os
+
 import numpy as np
 import pytest
 
@@ -127,6 +129,48 @@ def test_cfg3_8192_frame_host_to_host(gpu, scale_layers):
         assert (ys0 == 0 or y - 2 * ys0 >= 7) and (xs0 == 0 or x - 2 * xs0 >= 7)
         want = oracle_patch(o, up, y - 2 * ys0, x - 2 * xs0, 40, 40)
         assert_close(got[y:y + 40, x:x + 40], want, "cfg3 patch (%d,%d)" % (y, x))
+
+
+def test_cfg3_eight_units_host_gather(gpu, scale_layers):
+    """BASELINE.json configs[2] cut into EIGHT farm units (W2XC_HOST_BANDS=8: eight host threads, eight row ranges, eight pipes' worth of
+    staging -- what an 8-GPU node runs, here on the devices present): bit-identical to the one-unit result, and the host side's
+    scatter + gather rate (source rows in, output rows out, through the pinned rings) is printed so that the 8-unit host cost is a
+    number before a node exists."""
+    import time
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    rng = np.random.default_rng(8)
+    small = np.empty((8192, 8192), np.float32)
+    for r in range(0, 8192, 1024):
+        small[r:r + 1024] = rng.integers(0, 256, size=(1024, 8192), dtype=np.uint8).astype(np.float32) / np.float32(255)
+    one = ms.convert_nn2x(small)
+    os.environ["W2XC_HOST_BANDS"] = "8"
+    os.environ["W2XC_HOST_TRACE"] = "1"
+    try:
+        ms.convert_nn2x(small[:64])                      # (pipes of the extra units warm)
+        t0 = time.perf_counter()
+        eight = ms.convert_nn2x(small)
+        dt = time.perf_counter() - t0
+    finally:
+        del os.environ["W2XC_HOST_BANDS"], os.environ["W2XC_HOST_TRACE"]
+    assert np.array_equal(one, eight)
+    moved = small.nbytes + eight.nbytes
+    print("cfg3, 8 units on %d device(s): %.3f s for the 7-layer model (%.2f GB of planes through the staging rings)" % (gpu.device_count(), dt, moved / 1e9))
+    # the host side alone: the same 8-unit scatter / gather with a ONE-layer 1 -> 1 model (a fraction of a millisecond of kernel time per
+    # unit), i.e. pageable plane -> pinned ring -> H2D and D2H -> pinned ring -> pageable plane, nJob staging threads
+    tiny = gpu._ModelSet.from_layers(gen_model.synth_layers([1, 1], 3))
+    os.environ["W2XC_HOST_BANDS"] = "8"
+    try:
+        tiny.convert_nn2x(small[:64])
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = tiny.convert_nn2x(small)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        del os.environ["W2XC_HOST_BANDS"]
+    assert out.shape == (16384, 16384) and np.isfinite(out[::97, ::89]).all()
+    print("cfg3, 8 units, host scatter + gather alone (one-layer model): %.3f s = %.1f GB/s of planes in + out (nJob = %d staging threads; "
+          "units on a shared device serialise: a lower bound on the rate an 8-GPU node's host side sustains)" % (min(ts), moved / 1e9 / min(ts), gpu.lib().w2xc_get_jobs()))
 
 
 def cascade_cpu_patch(noise_layers, scale_layers, y_plane, y, x, size):

@@ -331,6 +331,7 @@ def test_bench_two_ranks_shard_one_plane_on_the_hip_path(gpu, tmp_path):
     j = run_bench(["--height", "96", "--width", "128", "--steps", "2", "--warmup", "1", "--dump-out", d],
                   env={"W2XC_BENCH_BACKEND": "gloo"}, nproc=2)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["frames_per_step"] == 1
+    assert j["ranks_seen"] == 2 and len(j["rank_ms_per_step"]) == 2 and len(j["rank_devices"]) == 2 and all(v > 0 for v in j["rank_ms_per_step"])
     assert "row-sharded" in j["config"]["workload"] and j["value"] > 0 and j["value_host_to_host"] > 0
     assert j["host_to_host"]["max_abs_diff_vs_resident_output"] == 0.0
     assert j["weak"]["scaling"] == "weak" and j["weak"]["value"] > 0

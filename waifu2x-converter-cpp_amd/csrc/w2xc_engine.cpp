@@ -14,6 +14,8 @@
 #include "../../include/w2xc_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1096,6 +1098,72 @@ int pipe_init(HostPipe &p)
 }
 
 // grow-only device / pinned buffers; growing drains the pipe first (earlier calls may still use the old ones)
+// ---- NUMA placement of a device's host pipeline (multi-socket hosts: the pinned rings and the threads that fill / drain them belong
+// on the CPU node the GPU hangs off, or every staged byte crosses the inter-socket link twice).  W2XC_NUMA=0 disables. ----
+int numa_node_of_device(int dev)
+{
+    static const bool enabled = [] { const char *e = getenv("W2XC_NUMA"); return !(e && atoi(e) == 0); }();
+    if (!enabled) return -1;
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, dev) == hipSuccess && node >= 0) return node;
+    (void)hipGetLastError();
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *q = bus; *q; q++) *q = (char)tolower(*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// the CPUs of a node ("0-63,128-191" in /sys/devices/system/node/nodeN/cpulist); false when unknown or the node has none
+bool cpus_of_node(int node, cpu_set_t *set)
+{
+    if (node < 0) return false;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    CPU_ZERO(set);
+    int count = 0;
+    for (const char *q = buf; *q;) {
+        char *end = nullptr;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        q = end;
+        if (*q == '-') { b = strtol(q + 1, &end, 10); q = end; }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++) { CPU_SET((int)cpu, set); count++; }
+        while (*q == ',' || *q == '\n' || *q == ' ') q++;
+    }
+    return count > 0;
+}
+
+// Binds the calling thread to a device's CPU node for its lifetime and restores the previous affinity afterwards
+struct NodeAffinity {
+    cpu_set_t prev;
+    bool bound = false;
+    int node = -1;
+    explicit NodeAffinity(int dev)
+    {
+        node = numa_node_of_device(dev);
+        cpu_set_t want;
+        if (!cpus_of_node(node, &want)) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof prev, &prev) != 0) return;
+        cpu_set_t both;
+        CPU_AND(&both, &prev, &want);          // never leave the set the caller (or a cgroup) already confined us to
+        if (CPU_COUNT(&both) == 0) return;
+        bound = pthread_setaffinity_np(pthread_self(), sizeof both, &both) == 0;
+    }
+    ~NodeAffinity() { if (bound) pthread_setaffinity_np(pthread_self(), sizeof prev, &prev); }
+};
+
 int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot, size_t out_slot)
 {
     auto drain = [&]() -> int {
@@ -1119,14 +1187,14 @@ int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot,
     if (in_slot && p.in_slot_bytes < in_slot) {
         int rc = drain(); if (rc) return rc;
         if (p.pin_in) { HIP_TRY(hipHostFree(p.pin_in)); p.pin_in = nullptr; p.in_slot_bytes = 0; }
-        if (hipHostMalloc((void **)&p.pin_in, in_slot * HostPipe::IN_SLOTS, hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void **)&p.pin_in, in_slot * HostPipe::IN_SLOTS, hipHostMallocNumaUser) != hipSuccess)
             return fail(W2XC_ERR_NOMEM, "hipHostMalloc of the input staging ring failed");
-        p.in_slot_bytes = in_slot;
+        p.in_slot_bytes = in_slot;   // (hipHostMallocNumaUser: the pages follow the allocating thread's policy -- it is bound to the device's node)
     }
     if (out_slot && p.out_slot_bytes < out_slot) {
         int rc = drain(); if (rc) return rc;
         if (p.pin_out) { HIP_TRY(hipHostFree(p.pin_out)); p.pin_out = nullptr; p.out_slot_bytes = 0; }
-        if (hipHostMalloc((void **)&p.pin_out, out_slot * HostPipe::OUT_SLOTS, hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void **)&p.pin_out, out_slot * HostPipe::OUT_SLOTS, hipHostMallocNumaUser) != hipSuccess)
             return fail(W2XC_ERR_NOMEM, "hipHostMalloc of the output staging ring failed");
         p.out_slot_bytes = out_slot;
     }
@@ -1151,6 +1219,9 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     const float *in = (const float *)((const char *)in_ - (ptrdiff_t)in_row0 * (ptrdiff_t)in_stride);
     float *out = (float *)((char *)out_ - (ptrdiff_t)out_row0 * (ptrdiff_t)out_stride);
     HIP_TRY(hipSetDevice(dev));
+    // this thread is the unit's feeder: it (and the drainer it starts, which inherits the affinity) runs on the device's CPU node, and
+    // the pinned rings it allocates land there; the caller's affinity is restored on return
+    NodeAffinity node_guard(dev);
     DevCtx *c = nullptr;
     int rc = get_ctx(m, dev, &c);
     if (rc) return rc;
@@ -1339,8 +1410,9 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     if (trace) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
     std::string err = g_last_error;
     finish_drainer();
-    if (trace) fprintf(stderr, "[w2xc host] rows %d..%d: enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s)\n", ra, rb, t_enq, t_comp,
-                       ms_since(t0), in_pinned ? "pinned" : "pageable", out_pinned ? "pinned" : "pageable");
+    if (trace) fprintf(stderr, "[w2xc host] device %d (cpu node %d%s) rows %d..%d: enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s, %d copy threads)\n",
+                       dev, node_guard.node, node_guard.bound ? ", threads bound" : "", ra, rb, t_enq, t_comp,
+                       ms_since(t0), in_pinned ? "pinned" : "pageable", out_pinned ? "pinned" : "pageable", copy_threads);
     // leave nothing in flight, whatever happened: the pipe and the caller's planes are reused by the next call
     hipError_t e1 = hipStreamSynchronize(p.s_h2d), e2 = hipStreamSynchronize(p.s_compute), e3 = hipStreamSynchronize(p.s_d2h);
     if (rc) { g_last_error = err; return rc; }
@@ -1412,7 +1484,8 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         }
     }
     // modelUtility's nJob (modelHandler.hpp:99; the CLI's -j) = host threads that move rows in and out of the staging rings
-    const int copy_threads = std::max(1, std::min(w2xc_get_jobs(), 32) / nd);
+    // (at least two per unit: with the default nJob = 4 and 8 devices a single thread per device could not keep a 64 GB/s link busy)
+    const int copy_threads = std::max(nd > 1 ? 2 : 1, std::min(w2xc_get_jobs(), 32) / nd);
 
     int prev = 0;
     hipGetDevice(&prev);
