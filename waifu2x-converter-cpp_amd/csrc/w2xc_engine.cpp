@@ -1146,15 +1146,29 @@ bool cpus_of_node(int node, cpu_set_t *set)
 }
 
 // Binds the calling thread to a device's CPU node for its lifetime and restores the previous affinity afterwards
+struct NodeCpus { int node = -1; bool have = false; cpu_set_t set; };
+const NodeCpus &node_cpus_of_device(int dev)   // looked up once per device: no /sys read or attribute query on the per-call path
+{
+    static std::mutex mu;
+    static std::map<int, NodeCpus> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    NodeCpus nc;
+    nc.node = numa_node_of_device(dev);
+    nc.have = cpus_of_node(nc.node, &nc.set);
+    return cache.emplace(dev, nc).first->second;
+}
 struct NodeAffinity {
     cpu_set_t prev;
     bool bound = false;
     int node = -1;
     explicit NodeAffinity(int dev)
     {
-        node = numa_node_of_device(dev);
-        cpu_set_t want;
-        if (!cpus_of_node(node, &want)) return;
+        const NodeCpus &nc = node_cpus_of_device(dev);
+        node = nc.node;
+        if (!nc.have) return;
+        const cpu_set_t want = nc.set;
         if (pthread_getaffinity_np(pthread_self(), sizeof prev, &prev) != 0) return;
         cpu_set_t both;
         CPU_AND(&both, &prev, &want);          // never leave the set the caller (or a cgroup) already confined us to
