@@ -460,7 +460,10 @@ def main():
         def issued(l):   # fraction of a layer's algorithmic multiplies its kernel issues (Winograd F(2x2,3x3): 16 of 36)
             return 16.0 / 36.0 if "wino" in ms.kernel_name(l, opts) else 1.0
         algorithmic = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        achieved = algorithmic * issued(dom)
+        # a fused last layer's MFMAs are issued by the dominant kernel too (taps-as-rows on 16x16x4 tiles: 16 rows x cin per pixel, 9 of them useful)
+        fused_last = dom + 1 == n_layers - 1 and ms.kernel_name(dom + 1, opts) == "conv3x3_last_gather" and args.precision == "fp32"
+        fused_flops = (2.0 * 16 * ms.planes(dom + 1)[0] * dom_flops / (18.0 * ms.planes(dom)[0] * ms.planes(dom)[1])) if fused_last else 0.0
+        achieved = algorithmic * issued(dom) + (fused_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0)
         per_layer = []
         for l in range(n_layers):
             ms_l = layer_ms[l] / max(launches[l], 1) * nbands[l]
@@ -517,13 +520,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
                          "avg_launch_ms": round(dom_ms, 4), "mfma_products_per_fma": products,
-                         "flops_per_launch": dom_flops * products * issued(dom),
+                         "flops_per_launch": dom_flops * products * issued(dom) + fused_flops,
+                         "fused_last_layer_flops_per_launch": fused_flops,
                          "algorithmic_flops_per_launch": dom_flops,
                          "algorithmic_tflops": round(algorithmic, 3),
                          "algorithmic_speedup_vs_direct_roofline": round(algorithmic / peak, 4),
                          "note": ("Winograd F(2x2,3x3) issues 16/36 of the algorithmic multiplies: `achieved` / `frac` are the MFMA pipe's own rate (issued "
                                   "FLOPs / time / peak); `algorithmic_tflops` is SURVEY 8(d)'s FLOPs over the same time -- above the peak, i.e. faster than a "
-                                  "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs"),
+                                  "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs") +
+                                 ("; the launch also issues the fused last layer's MFMAs (`fused_last_layer_flops_per_launch`, +3 %), counted in `achieved` but "
+                                  "not in the algorithmic figures of THIS layer" if fused_last else ""),
                          "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,
             "output_finite": ok,

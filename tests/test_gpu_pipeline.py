@@ -317,7 +317,8 @@ def test_bench_line_single_gpu(gpu):
     # FLOPs over the same time) sits beside it and may pass the peak with a Winograd kernel on the dominant layer
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     assert r["algorithmic_tflops"] >= r["achieved"] - 1e-6 and abs(r["algorithmic_tflops"] / r["peak"] - r["algorithmic_speedup_vs_direct_roofline"]) < 1e-3
-    assert abs(r["flops_per_launch"] / r["algorithmic_flops_per_launch"] - (16 / 36 if "wino" in r["kernel"] else 1.0)) < 1e-9
+    assert abs((r["flops_per_launch"] - r["fused_last_layer_flops_per_launch"]) / r["algorithmic_flops_per_launch"] - (16 / 36 if "wino" in r["kernel"] else 1.0)) < 1e-9
+    assert r["fused_last_layer_flops_per_launch"] == (0 if j["layers"][6]["kernel"] == "conv3x3_last" else r["fused_last_layer_flops_per_launch"]) >= 0
     assert all(0 < l["frac_of_peak"] < 1 for l in j["layers"])
     assert ("conv3x3_wino" in r["kernel"] or "conv3x3_mfma" in r["kernel"]) and "128->128" in r["kernel"]
     assert len(j["layers"]) == 7 and "workload" in j["config"]

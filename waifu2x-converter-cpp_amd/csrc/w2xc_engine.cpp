@@ -689,6 +689,11 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     d.out_gs = (long long)d.out_h * d.out_w;
                     d.out_ts = 9 * d.out_gs;
                     d.halves = fused_halves(T, hl.nout);
+                    if (T == 0) {   // fp32 (conv3x3_wino16): the partials interleaved, G[tap][y][x][half] -- the gather reads 16 bytes per tap and pixel
+                        d.out_ps = d.halves; d.out_rs = (long long)d.out_w * d.halves;
+                        d.out_gs = (long long)d.out_h * d.out_w * d.halves;
+                        d.out_ts = 1;
+                    }
                 }
             }
             // 16-bit modes, host pipeline: the last layer lives in layer n-1's epilogue + a 0.2 ms gather, too short to hide the

@@ -973,7 +973,7 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
 // ---- last layer fused into the epilogue of the two-term kernels (out_terms = 9) ----
 // conv3x3_last_gather: out(y,x) = leaky(bias + sum over taps (ty,tx) and wave-column halves of G[half][tap][y+ty][x+tx]),
 // G = [halves][9][gh][gw] fp32 tap planes as written by conv3x3_split<.., OT = 9>; (gh, gw) = (out_h + 2, out_w + 2).
-__global__ void __launch_bounds__(256) conv3x3_last_gather(const float *G, int halves, long long hs, long long ps, long long rs,
+__global__ void __launch_bounds__(256) conv3x3_last_gather(const float *G, int halves, long long hs, long long ps, long long rs, long long xs,
                                                            const float *bias, float *out, long long out_rs, long long out_ps, int out_h, int out_w)
 {
     const long long total = (long long)out_h * out_w;
@@ -982,9 +982,30 @@ __global__ void __launch_bounds__(256) conv3x3_last_gather(const float *G, int h
         float v = 0.0f;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const float *g = G + tap * ps + (long long)(y + tap / 3) * rs + (x + tap % 3);
+            const float *g = G + tap * ps + (long long)(y + tap / 3) * rs + (long long)(x + tap % 3) * xs;
             for (int hf = 0; hf < halves; hf++) v += g[hf * hs];
         }
+        out[(long long)y * out_rs + (long long)x * out_ps] = leaky(v + bias[0]);
+    }
+}
+
+// The same sum for partial planes stored INTERLEAVED, G[tap][y][x][H] (the fp32 fused last layer of conv3x3_wino16 writes that: half stride 1,
+// pixel stride H): one 8- / 16-byte load per tap and pixel instead of H dwords from H planes, fully coalesced.
+template <int H>
+__global__ void __launch_bounds__(256) conv3x3_last_gather_il(const float *G, long long ps, long long rs, const float *bias, float *out, long long out_rs,
+                                                              long long out_ps, int out_h, int out_w)
+{
+    typedef float vecH __attribute__((ext_vector_type(H)));
+    const long long total = (long long)out_h * out_w;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int y = (int)(idx / out_w), x = (int)(idx - (long long)y * out_w);
+        vecH acc = {};
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+            acc += *reinterpret_cast<const vecH *>(G + tap * ps + (long long)(y + tap / 3) * rs + (long long)(x + tap % 3) * H);
+        float v = 0.0f;
+#pragma unroll
+        for (int h = 0; h < H; h++) v += acc[h];
         out[(long long)y * out_rs + (long long)x * out_ps] = leaky(v + bias[0]);
     }
 }
@@ -994,7 +1015,14 @@ hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     const long long total = (long long)d.out_h * d.out_w;
     int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(conv3x3_last_gather, dim3(grid), dim3(256), 0, stream, d.in, d.halves, d.in_ts, d.in_gs, d.in_rs, d.bias, d.out,
+    if (d.in_ts == 1 && d.in_ps == d.halves && (d.halves == 2 || d.halves == 4) && ((size_t)d.in % (4 * d.halves)) == 0 && (d.in_rs % d.halves) == 0 && (d.in_gs % d.halves) == 0) {
+        if (d.halves == 4)
+            hipLaunchKernelGGL(conv3x3_last_gather_il<4>, dim3(grid), dim3(256), 0, stream, d.in, d.in_gs, d.in_rs, d.bias, d.out, d.out_rs, d.out_ps, d.out_h, d.out_w);
+        else
+            hipLaunchKernelGGL(conv3x3_last_gather_il<2>, dim3(grid), dim3(256), 0, stream, d.in, d.in_gs, d.in_rs, d.bias, d.out, d.out_rs, d.out_ps, d.out_h, d.out_w);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(conv3x3_last_gather, dim3(grid), dim3(256), 0, stream, d.in, d.halves, d.in_ts, d.in_gs, d.in_rs, d.in_ps > 0 ? d.in_ps : 1, d.bias, d.out,
                        d.out_rs, d.out_ps, d.out_h, d.out_w);
     return hipGetLastError();
 }

@@ -58,7 +58,7 @@ __device__ unsigned long long w16_stamps[2][4096];
 // 64 = patch reads but no transform additions; 2048 = epilogue at normal priority; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
 // FUSE: the NEXT layer is the model's last one with ONE output plane (every waifu2x model): it is computed in this kernel's epilogue
 // ("taps as rows": G[tap][pixel] = sum_c W_last[c][tap] act[c][pixel], 32 more MFMAs per item and wave, on the activations the epilogue
-// has just produced) and `out` receives the partial tap planes G[32-plane block][tap][y][x] (d.out_ts / out_gs / out_rs) that
+// has just produced) and `out` receives the partial tap planes G[32-plane block][tap][y][x] (strides d.out_ts / out_gs / out_rs / out_ps) that
 // conv3x3_last_gather sums -- 144 instead of 512 bytes per pixel written, and the 512 the last layer would read never exist.
 template <int CIN, int COUT, int ABL = 0, bool FUSE = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int tiles_x, int nitems)
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                 }
                 if constexpr (FUSE) {
                     // D layout of G: lane & 15 = block, register e = tap 4 k + e (k = 0, 1: four taps; k = 2: tap 8; k = 3: none)
-                    float *gbase = d.out + (long long)ob * d.out_ts + (long long)(4 * k) * d.out_gs + (long long)oy * d.out_rs + ox;
+                    float *gbase = d.out + (long long)ob * d.out_ts + (long long)(4 * k) * d.out_gs + (long long)oy * d.out_rs + (long long)ox * d.out_ps;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if (4 * k + e < 9) {
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
 #pragma unroll
                                 for (int j = 0; j < 2; j++)
                                     if (interior || (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w))
-                                        gbase[(long long)e * d.out_gs + (long long)i * d.out_rs + j] = gacc[i][j][e];
+                                        gbase[(long long)e * d.out_gs + (long long)i * d.out_rs + (long long)j * d.out_ps] = gacc[i][j][e];
                         }
                     }
                 }
