@@ -1535,7 +1535,7 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     }
     hipSetDevice(prev);
     for (int t = 0; t < nd; t++)
-        if (rcs[t]) { g_last_error = errs[t]; std::cerr << errs[t] << std::endl; return rcs[t]; }
+        if (rcs[t]) { g_last_error = errs[t]; return rcs[t]; }   // (the message is w2xc_last_error(); the C++ adapter prints it, a C-ABI consumer decides itself)
     return W2XC_OK;
 }
 }  // namespace
