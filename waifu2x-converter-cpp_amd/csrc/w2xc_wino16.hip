@@ -79,6 +79,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
     constexpr unsigned LOFS_BASE = U_BASE + 4 * U_BYTES;
     constexpr unsigned BIAS_BASE = LOFS_BASE + APW * 512 * 4;
     static_assert(CIN % 16 == 0 && NSP >= 2 && COUT % 64 == 0, "planes");
+    // Pixel tiles are walked in STRIPS of 16 tiles (512 pixels) across, row by row inside a strip: the 32 CUs of an XCD work on 16 neighbouring
+    // tiles x 2 items at a time, so the next round of an XCD is the tile row BELOW -- whose two halo rows are then still in that XCD's L2
+    // (a plain row-major walk re-reads them from HBM a whole plane row later: 1.33x the plane, measured).
+    constexpr int STRIP = 16;
+    const int tiles_y = nitems / (NOB * tiles_x);
+    auto tile_coords = [&](int pt, int &ty_, int &tx_) {
+        const int per_strip = STRIP * tiles_y;
+        int sidx = pt / per_strip;
+        const int nfull = tiles_x / STRIP;
+        if (sidx > nfull) sidx = nfull;                          // (the last, narrower strip)
+        const int wid = sidx < nfull ? STRIP : tiles_x - nfull * STRIP;
+        const int q = pt - sidx * per_strip;
+        ty_ = q / wid;
+        tx_ = sidx * STRIP + (q - ty_ * wid);
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
@@ -127,7 +142,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
     const char *a_base;
     auto tile_offsets = [&](int it) {
         const int pt = it / NOB;
-        const int ty_ = pt / tiles_x, tx_ = pt - ty_ * tiles_x;
+        int ty_, tx_;
+        tile_coords(pt, ty_, tx_);
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
         const int yb = clampi(y0, 0, d.in_h - 1), xb = clampi(x0, 0, d.in_w - 1);
         a_base = reinterpret_cast<const char *>(d.in) + ((ABL & 512) ? 0ll : ((long long)yb * d.in_rs + (long long)xb * CIN) * 4);
@@ -354,7 +370,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16(W2xcConvDesc d, int til
                 // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
                 //      C/D of the 16x16 MFMA: lane & 15 = block, register e = plane 4 * (lane >> 4) + e of the plane tile ----
                 const int ob = (item % NOB) * 2 + grp, ptile = item / NOB;
-                const int tile_y = ptile / tiles_x, tile_x = ptile - tile_y * tiles_x;
+                int tile_y, tile_x;
+                tile_coords(ptile, tile_y, tile_x);
                 const int ty0 = tile_y * ROWS - d.wino_py;
                 const int oy = ty0 + 2 * brow, ox = tile_x * 32 + 2 * t;
                 float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * k;
