@@ -54,6 +54,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     constexpr unsigned B_BYTES = 32 * 1024;                // U of one (plane block, slice)
     constexpr unsigned B_BASE = 2 * A_BYTES;
     static_assert(CIN % 16 == 0 && COUT % 32 == 0, "planes");
+    // pixel tiles are walked in strips of 32 tiles, row by row inside a strip (conv3x3_wino16 explains: the next round of an XCD is the tile
+    // row below, whose halo rows are still in that XCD's L2)
+    constexpr int STRIP = 32;
+    const int tiles_y = nitems / (NOB * tiles_x);
+    auto tile_coords = [&](int pt, int &ty_, int &tx_) {
+        const int per_strip = STRIP * tiles_y;
+        int sidx = pt / per_strip;
+        const int nfull = tiles_x / STRIP;
+        if (sidx > nfull) sidx = nfull;
+        const int wid = sidx < nfull ? STRIP : tiles_x - nfull * STRIP;
+        const int q = pt - sidx * per_strip;
+        ty_ = q / wid;
+        tx_ = sidx * STRIP + (q - ty_ * wid);
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const char *ldsb = reinterpret_cast<const char *>(lds);
@@ -99,7 +113,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     }
     auto tile_offsets = [&](int it) {
         const int pt = it / NOB;
-        const int ty_ = pt / tiles_x, tx_ = pt - ty_ * tiles_x;
+        int ty_, tx_;
+        tile_coords(pt, ty_, tx_);
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
         if (y0 >= 0 && y0 + HH <= d.in_h && x0 >= 0 && x0 + HW <= d.in_w) {   // wave-uniform
             const unsigned base = (unsigned)(((long long)y0 * d.in_rs + (long long)x0 * CIN) >> 2);
@@ -276,7 +291,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias, LeakyReLU, NHWC stores.
             //      C/D: lane&31 = block column (this lane's 2x2 block), register r = plane (r&3) + 8*(r>>2) + 4*(lane>>5) ----
             const int ob = item % NOB, pt = item / NOB;
-            const int tile_y = pt / tiles_x, tile_x = pt - tile_y * tiles_x;
+            int tile_y, tile_x;
+            tile_coords(pt, tile_y, tile_x);
             const int oy = tile_y * ROWS - d.wino_py + 4 * wave + 2 * tyl, ox = tile_x * 32 + 2 * tx;
             float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * kk;
             const int ty0 = tile_y * ROWS - d.wino_py;
