@@ -518,7 +518,9 @@ def main():
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes": int((ms.planes(dom)[0] + ms.planes(dom)[1]) * 4 * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
+                         # fp32 NHWC: Cin*4 read + Cout*4 written per pixel; with the last layer fused the launch writes Cout/32 x 9 partial tap values instead
+                         "algorithmic_bytes": int((ms.planes(dom)[0] * 4 + (ms.planes(dom)[1] // 32 * 9 * 4 if fused_last else ms.planes(dom)[1] * 4))
+                                                  * dom_flops / (18 * ms.planes(dom)[0] * ms.planes(dom)[1])),
                          "avg_launch_ms": round(dom_ms, 4), "mfma_products_per_fma": products,
                          "flops_per_launch": dom_flops * products * issued(dom) + fused_flops,
                          "fused_last_layer_flops_per_launch": fused_flops,

@@ -38,9 +38,9 @@ for k, (cin, cout) in enumerate(PLANES, 1):
             continue                                   # computed inside layer 2's kernel
         if fused12 and k == 2:
             sub = "conv3x3_first2_split<%d," % cout   # layers 1 + 2 in one kernel
-        if k == NL and any(n.startswith("conv3x3_last_gather") for n in stats):
+        if k == NL and any("conv3x3_last_gather" in n for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
-    if T == 0 and k == NL and any(n.startswith("conv3x3_last_gather") for n in stats):
+    if T == 0 and k == NL and any("conv3x3_last_gather" in n for n in stats):
         sub = "conv3x3_last_gather"   # fp32: the last layer inside conv3x3_wino16's epilogue + this gather (w2xc_opts.fusion)
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
     if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino16<CIN, COUT, 0> / conv3x3_wino<CIN, COUT>)
@@ -59,14 +59,14 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     in_bpe = 4 if (T == 0 or k == 1 or k == NL) else 2 * T
     out_bpe = 4 if (T == 0 or k >= NL - 1) else 2 * T
     alg = (cin * in_bpe + cout * out_bpe) * px
-    fused_fp32 = T == 0 and any(n.startswith("conv3x3_last_gather") for n in stats)
+    fused_fp32 = T == 0 and any("conv3x3_last_gather" in n for n in stats)
     if sub == "conv3x3_last_gather":
         alg = ((PLANES[NL - 2][1] // 32 if T == 0 else 2) * 9 * 4 + 4) * px   # partial tap planes in (Cout / 32 blocks, or two halves), one plane out
     if fused_fp32 and k == NL - 1:
         alg = (cin * 4 + (cout // 32) * 9 * 4) * px     # fused: writes the partial tap planes instead of cout fp32 planes
     if T > 0 and k == 2 and any("conv3x3_first2_split" in n for n in stats):
         alg = (4 + cout * out_bpe) * px                 # reads the input plane, layer 1's activations never reach HBM
-    if T > 0 and k == NL - 1 and any(n.startswith("conv3x3_last_gather") for n in stats):
+    if T > 0 and k == NL - 1 and any("conv3x3_last_gather" in n for n in stats):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     wino = "conv3x3_wino" in name
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": 16.0 / 36.0 if wino else 1.0,
