@@ -9,6 +9,7 @@
 // A tiny persistent pool: copy_rows() splits one strided row copy into `parts` contiguous row ranges,
 // the caller takes part in its own job, idle workers help.  Several device threads may submit at once.
 #pragma once
+#include <pthread.h>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -59,8 +60,18 @@ class CopyPool {
 public:
     static CopyPool &get()
     {
-        static CopyPool *p = new CopyPool();   // leaked on purpose: workers may outlive static destruction
+        static CopyPool *p = [] {
+            // after fork() the child has this object but none of its (detached) worker threads, and mu_ may be held by a thread that
+            // does not exist there: the child copies inline (nothing to lock, nothing to wake)
+            pthread_atfork(nullptr, nullptr, [] { forked().store(true, std::memory_order_relaxed); });
+            return new CopyPool();   // leaked on purpose: workers may outlive static destruction
+        }();
         return *p;
+    }
+    static std::atomic<bool> &forked()
+    {
+        static std::atomic<bool> f{false};
+        return f;
     }
 
     // dst/src rows are `row_bytes` long, `ds` / `ss` bytes apart.  nthreads <= 1 copies inline.
@@ -71,7 +82,7 @@ public:
         int parts = nthreads;
         if ((size_t)parts > total / (256u << 10)) parts = (int)(total / (256u << 10));   // >= 256 KiB per part
         if (parts > rows) parts = rows;
-        if (parts <= 1) {
+        if (parts <= 1 || forked().load(std::memory_order_relaxed)) {
             run(dst, ds, src, ss, row_bytes, 0, rows);
             return;
         }
@@ -85,7 +96,7 @@ public:
         }
         cv_.notify_all();
         work_on(*j);
-        for (int spin = 0; spin < 20000 && j->done.load(std::memory_order_acquire) != j->parts; spin++) {
+        for (int spin = 0; spin < 5000 && j->done.load(std::memory_order_acquire) != j->parts; spin++) {   // (~0.2 ms, then sleep)
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -139,7 +150,7 @@ private:
             std::shared_ptr<Job> j;
             // jobs arrive in bursts (one per staged chunk, ~100 us apart while a plane streams through the rings): poll for
             // a short while before sleeping, a condition-variable wake-up costs more than the copy of a 256 KiB part
-            for (int spin = 0; spin < 20000 && pending_.load(std::memory_order_acquire) == 0; spin++) {
+            for (int spin = 0; spin < 5000 && pending_.load(std::memory_order_acquire) == 0; spin++) {   // (~0.2 ms: two chunk intervals)
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif

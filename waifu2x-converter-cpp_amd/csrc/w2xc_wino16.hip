@@ -18,8 +18,9 @@
 //              Lane (t = lane & 15, k = lane >> 4): block t of the row; K index k of the MFMA = channels 2k, 2k+1 of a slice.
 //   Stage      one 8-channel slice: 2 steps (channel 2k + st in lane quarter k) x 16 xi x 2 plane tiles = 64 MFMAs = 2048 cycles
 //              per wave.  A lane reads its 4x4 patch once per stage (16 ds_read_b64 = both channels), transforms both channels with
-//              packed additions, and every V value feeds two MFMAs (plane tiles 0 and 1).  The patch of stage s+1 is read and
-//              transformed under the MFMAs of stage s.
+//              64 SCALAR additions in four bunches of 16 (beside the fp32 MFMA a VALU instruction costs 2 matrix-pipe cycles + ~4.5 per
+//              MFMA gap that holds VALU at all, packing buys nothing: tools/ubench/mfma_fillers.hip), and every V value feeds two
+//              MFMAs (plane tiles 0 and 1).  The patch of stage s+1 is read and transformed under the MFMAs of stage s.
 //   LDS        A[3] x 27 KiB: the 10 x 34 pixel halo tile of a 16-CHANNEL slice (two stages), pixel-major: a pixel's four 16-byte
 //              chunks + one pad slot = 80 B, pixels of a row even columns first, then odd ones.  The 80-byte stride makes the 16
 //              lanes of a quarter (blocks 2 pixels apart = consecutive positions) hit 16 different bank quads (5 t mod 16), the
@@ -31,8 +32,12 @@
 //   Transfers  SGPR base + 32-bit lane offset; per wave and stage 4 U pieces (own group, one stage ahead), and every second stage 4 tile
 //              pieces (two 16-channel slices ahead); U first, tile pieces last, so the stage's closing COUNTED vmcnt leaves the
 //              tile pieces in flight.
-//   Epilogue   output transform, bias, LeakyReLU, 16-byte NHWC stores (a lane holds 4 consecutive planes of its block's 4 pixels).
+//   Epilogue   output transform on register pairs, bias, LeakyReLU (one v_med3), 16-byte NHWC stores (a lane holds 4 consecutive planes of
+//              its block's 4 pixels), at raised wave priority; FUSE: the one-plane last layer on the fresh activations (below).
+//   Tile walk  strips of 16 tiles, row by row inside a strip: an XCD's next round is the tile row below, its halo rows still in L2.
 //   Banding    blocks sit on EVEN rows of the layer's whole output (W2xcConvDesc::wino_py), as in conv3x3_wino.
+// Measured (round 3, 2160x3840, profiles/r3_*): 128->128 8.7-8.9 ms (conv3x3_wino 9.6, conv3x3_mfma2 16.9) = 0.78-0.80 of the fp32 MFMA peak on the
+// multiplies it issues, SQ_LDS_BANK_CONFLICT ~ 0, HBM traffic 1.03-1.18x algorithmic, no register spills; what the rest is: DESIGN.md 3.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
