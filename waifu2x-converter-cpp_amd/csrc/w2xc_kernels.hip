@@ -382,7 +382,9 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     constexpr int ROWS = 8, MB = 2, HW = 34, HH = ROWS + 2;
     constexpr int K = 9 * CIN, S = (K + 1) / 2;
     constexpr int COUT = 32 * NBT;
+    constexpr int TPS = 36;   // floats per pixel in the store-transpose tile: 32 planes + 4 pad (144-byte stride: conflict-free 16-byte writes)
     __shared__ float lds[CIN * HH * HW];
+    __shared__ __attribute__((aligned(16))) float tps[4 * MB * 32 * TPS];   // per wave: its MB rows x 32 pixels x 32 planes
 
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
@@ -432,20 +434,29 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[mb][s], acc[mb], 0, 0, 0);
-        const int x = ox0 + i;
+        // Stores: a lane holds 4 x 4 consecutive planes of ONE pixel, so direct stores write 32-byte pieces of 32 different cache lines per
+        // instruction -- 3.4-3.6 TB/s where a pure write stream reaches 6.9 (tools/ubench/hbm_streams.py).  The wave's MB x 32 pixels x 32
+        // planes go through LDS instead (own region, no workgroup barrier) and leave as whole lines: 8 consecutive lanes = one pixel's
+        // 128 bytes, 64 lanes = 8 pixels (1 KiB contiguous when COUT = 32).
+        float *tw = tps + wave * (MB * 32 * TPS);
 #pragma unroll
-        for (int mb = 0; mb < MB; mb++) {
-            const int y = oy0 + wave * MB + mb;
-            if (y < d.out_h && x < d.out_w) {
-                float *op = d.out + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * kk;
+        for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    f32x4 v;
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e]);
-                    *reinterpret_cast<f32x4 *>(op + 8 * q) = v;
-                }
+                for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e]);
+                *reinterpret_cast<f32x4 *>(tw + (mb * 32 + i) * TPS + 8 * q + 4 * kk) = v;
             }
+#pragma unroll
+        for (int n = 0; n < MB * 4; n++) {
+            const int c = n * 64 + lane;             // 16-byte chunk c of the wave's MB x 32 x 8 chunks
+            const int p = c >> 3, ch = c & 7;         // pixel p = mb * 32 + x, chunk ch of its 32 planes
+            const int mb = p >> 5, px = p & 31;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tw + p * TPS + 4 * ch);
+            const int y = oy0 + wave * MB + mb, x = ox0 + px;
+            if (y < d.out_h && x < d.out_w)
+                *reinterpret_cast<f32x4 *>(d.out + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * ch) = v;
         }
     }
 }
