@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
                             const float v = acc[mb][nb][r] + bv[nb];
-                            obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                            obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = __builtin_amdgcn_fmed3f(v, 0.1f * v, 3.402823466e+38f);
                             acc[mb][nb][r] = 0.0f;
                         }
                 epi_stores = true;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
                             const int x = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                             const float v = acc[mb][nb][r] + bv[nb];
                             if (y < d.out_h && x < d.out_w)
-                                obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = fmaxf(v, 0.1f * v);
+                                obase[(long long)mb * d.out_rs + ((r & 3) + 8 * (r >> 2)) * COUT + nb * 32] = __builtin_amdgcn_fmed3f(v, 0.1f * v, 3.402823466e+38f);
                             acc[mb][nb][r] = 0.0f;
                         }
                 }
