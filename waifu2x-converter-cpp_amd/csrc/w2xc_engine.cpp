@@ -717,18 +717,26 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     int rc = launch_layer(c, m, k - 1, kind, dd, st, o);
                     if (rc) return rc;
                     g_done = g1;
-                    W2xcConvDesc dg;
-                    memset(&dg, 0, sizeof dg);
-                    dg.in = d.out + (size_t)r0 * d.out_rs; dg.in_rs = d.out_rs; dg.in_ps = d.out_ps; dg.in_cs = d.out_cs;
-                    dg.in_ts = d.out_ts; dg.in_gs = d.out_gs; dg.halves = d.halves; dg.fmt = d.fmt;
-                    dg.in_h = r1 - r0 + 2; dg.in_w = d.out_w;
-                    dg.out_h = r1 - r0; dg.out_w = w;
-                    dg.out = d_out + (size_t)(y0 - ra + r0) * out_stride_f;
-                    dg.out_rs = (long long)out_stride_f; dg.out_ps = 1; dg.out_cs = out_cs;
-                    rc = launch_layer(c, m, n - 1, W2XC_K_LAST_GATHER, dg, st, o);
-                    if (rc) return rc;
-                    rc = hk->output_ready(y0 + r0, y0 + r1);
-                    if (rc) return rc;
+                    // the gather of the chunk's rows; the LAST chunk's gather in pieces of ~128 rows, each handed to the download as soon as it
+                    // is enqueued: what nothing can hide is then the download + stitch of the last ~2 MB piece, not of the whole last chunk
+                    const int piece = (r1 == R && r1 - r0 > 192) ? 128 : r1 - r0;
+                    for (int a = r0; a < r1;) {
+                        int b = std::min(r1, a + piece);
+                        if (r1 - b < 64) b = r1;
+                        W2xcConvDesc dg;
+                        memset(&dg, 0, sizeof dg);
+                        dg.in = d.out + (size_t)a * d.out_rs; dg.in_rs = d.out_rs; dg.in_ps = d.out_ps; dg.in_cs = d.out_cs;
+                        dg.in_ts = d.out_ts; dg.in_gs = d.out_gs; dg.halves = d.halves; dg.fmt = d.fmt;
+                        dg.in_h = b - a + 2; dg.in_w = d.out_w;
+                        dg.out_h = b - a; dg.out_w = w;
+                        dg.out = d_out + (size_t)(y0 - ra + a) * out_stride_f;
+                        dg.out_rs = (long long)out_stride_f; dg.out_ps = 1; dg.out_cs = out_cs;
+                        rc = launch_layer(c, m, n - 1, W2XC_K_LAST_GATHER, dg, st, o);
+                        if (rc) return rc;
+                        rc = hk->output_ready(y0 + a, y0 + b);
+                        if (rc) return rc;
+                        a = b;
+                    }
                     r0 = r1;
                 }
                 break;
