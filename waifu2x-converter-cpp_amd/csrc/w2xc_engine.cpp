@@ -403,7 +403,7 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 // fp32 path, layers with 32 / 64 / 128 planes in and out (W2XC_K_MFMA): which kernel runs them.
 //   MID_MFMA    conv3x3_mfma2: direct implicit GEMM, a k-ordered fp32 fma chain (the closest MFMA analogue of modelHandler.cpp:134-145)
 //   MID_WINO32  conv3x3_wino:   Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, one wave per SIMD (round 2)
-//   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two workgroups per CU (round 3)
+//   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD (round 3; 64 / 128 output planes)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
 // _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel unless W2XC_WINO_KERNEL=32.
@@ -1110,7 +1110,6 @@ int pipe_init(HostPipe &p)
     return W2XC_OK;
 }
 
-// grow-only device / pinned buffers; growing drains the pipe first (earlier calls may still use the old ones)
 // ---- NUMA placement of a device's host pipeline (multi-socket hosts: the pinned rings and the threads that fill / drain them belong
 // on the CPU node the GPU hangs off, or every staged byte crosses the inter-socket link twice).  W2XC_NUMA=0 disables. ----
 int numa_node_of_device(int dev)
@@ -1191,6 +1190,7 @@ struct NodeAffinity {
     ~NodeAffinity() { if (bound) pthread_setaffinity_np(pthread_self(), sizeof prev, &prev); }
 };
 
+// grow-only device / pinned buffers; growing drains the pipe first (earlier calls may still use the old ones)
 int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot, size_t out_slot)
 {
     auto drain = [&]() -> int {
