@@ -58,9 +58,11 @@ __device__ unsigned long long w16_stamps[2][4096];
 #define W16_STAMP(idx) do { } while (0)
 #endif
 
-// ABL: timing-only ablations (wrong results; -DW16_ABLATE builds): 1 = no U transfers in the stage loop, 2 = no tile transfers,
-// 4 = no epilogue stores, 8 = no stage barrier, 16 = no patch reads / input transform, 32 = no U fragment reads,
-// 64 = patch reads but no transform additions; 2048 = epilogue at normal priority; 512 = tile transfers always read the first tile (L2 hits); 1024 = tile pieces early in the stage; 128 = VARIANT (correct): accumulators forced into AGPRs (inline-asm MFMA)
+// ABL: timing-only ablations (wrong results; -DW16_ABLATE builds, W2XC_W16_ABL=<bits> picks one at run time, profiles/r3_sweeps.log has the numbers):
+//   1 no U transfers in the stage loop | 2 no tile transfers | 4 no epilogue stores | 8 no stage barrier | 16 no patch reads / input transform |
+//   32 no U fragment reads | 64 patch reads but no transform additions | 512 tile transfers always read the first tile (L2 hits) |
+//   1024 tile pieces early in the stage | 2048 epilogue at normal priority | 256 transform additions two per MFMA gap instead of four bunches of 16 |
+//   128 a correct VARIANT: accumulators forced into AGPRs (inline-asm MFMA)
 // FUSE: the NEXT layer is the model's last one with ONE output plane (every waifu2x model): it is computed in this kernel's epilogue
 // ("taps as rows": G[tap][pixel] = sum_c W_last[c][tap] act[c][pixel], 32 more MFMAs per item and wave, on the activations the epilogue
 // has just produced) and `out` receives the partial tap planes G[32-plane block][tap][y][x] (strides d.out_ts / out_gs / out_rs / out_ps) that
