@@ -197,7 +197,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dist = None
     backend = os.environ.get("W2XC_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" for the 1-GPU self-test
-    if world > 1:
+    # W2XC_BENCH_FORCE_PG=1 (test aid): create the process group even for ONE rank, so that the RCCL initialisation, barrier,
+    # all_reduce and all_gather of the N > 1 path run on a single-GPU box (two ranks cannot share a device under RCCL)
+    if world > 1 or os.environ.get("W2XC_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -324,6 +324,20 @@ def test_bench_line_single_gpu(gpu):
     assert len(j["layers"]) == 7 and "workload" in j["config"]
 
 
+def test_bench_rccl_process_group_one_rank(gpu):
+    """the N > 1 code of bench.py on the REAL backend ("nccl" = RCCL): a one-rank process group under torch.distributed.run, so that the
+    RCCL initialisation (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0), the barrier, the MAX all_reduce and the all_gather of the per-rank
+    figures have run on this image before a multi-GPU node sees them (two ranks cannot share a device under RCCL: that is the gloo test)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "plane", "--height", "96", "--width", "128", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]   # (the row-sharded workload of N > 1, here with one shard)
+    r = subprocess.run(cmd, env=dict(os.environ, W2XC_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["ranks_seen"] == 1 and j["backend"] == "nccl" and len(j["rank_ms_per_step"]) == 1 and j["value"] > 0 and j["output_finite"]
+    assert j["scaling"] == "strong" and "row-sharded" in j["config"]["workload"] and j["host_to_host"]["max_abs_diff_vs_resident_output"] == 0.0
+
+
 def test_bench_two_ranks_shard_one_plane_on_the_hip_path(gpu, tmp_path):
     """N = 2 (two ranks on this GPU, gloo for the barrier): the default workload is ONE frame row-sharded over the ranks on
     the HIP path -- strong scaling, the weak figure beside it -- and the rows the ranks produced stitch to the oracle's plane"""
