@@ -171,6 +171,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     __builtin_amdgcn_s_barrier();
 
     unsigned abuf = 0, bbuf = 0;
+    // (a trip count the compiler cannot see: with NSL = 2 it otherwise peels the one-iteration slice loop into the item loop and spills 31 registers)
+    const int nsl_rt = NSL + (d.in_shift & 0x40000000);
     for (;;) {
       // The accumulators are DEFINED by the first stage of an item (its first 16 MFMAs take C = 0) and die in the epilogue: carried
       // across items they are 256 loop-carried registers whose phi copies the allocator routes through VGPRs and scratch.
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
       };
       stage(std::true_type{}, 0);
 #pragma unroll 1
-      for (int sl = 1; sl < NSL; sl++) stage(std::false_type{}, sl);
+      for (int sl = 1; sl < nsl_rt; sl++) stage(std::false_type{}, sl);
         {
             // the hazard recogniser does not see inside inline asm: let the last MFMAs drain (16 passes) before VALU reads their results
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
