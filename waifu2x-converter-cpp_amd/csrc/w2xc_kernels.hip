@@ -376,6 +376,9 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_mfma2(W2xcCon
 //   Packed weights: wpk[nb][s][lane] = W[32*nb + (lane&31)][c][tap] for k = 2*s + (lane>>5) < K, else 0.
 //   Workgroup = 4 waves, tile = 8 rows x 32 pixels; wave w owns rows 2w, 2w+1.
 // ------------------------------------------------------------------------------------------------
+#ifndef FIRST_TPW
+#define FIRST_TPW 4
+#endif
 template <int CIN, int NBT>
 __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x, int ntiles)
 {
@@ -386,11 +389,16 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     __shared__ float lds[CIN * HH * HW];
     __shared__ __attribute__((aligned(16))) float tps[4 * MB * 32 * TPS];   // per wave: its MB rows x 32 pixels x 32 planes
 
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+    // a workgroup walks FIRST_TPW consecutive tiles (a write-bound kernel of 32 791 four-wave workgroups was bound by their turnover)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_base = xcd_remap(blockIdx.x, (ntiles + FIRST_TPW - 1) / FIRST_TPW) * FIRST_TPW;
+  for (int it = 0; it < FIRST_TPW; it++) {
+    const int tile = tile_base + it;
+    if (tile >= ntiles) break;                       // (workgroup-uniform)
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+    if (it) __syncthreads();                         // the previous tile's patch reads are done
 
     for (int idx = threadIdx.x; idx < CIN * HH * HW; idx += 256) {
         const int c = idx / (HH * HW), p = idx - c * (HH * HW);
@@ -459,6 +467,7 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
                 *reinterpret_cast<f32x4 *>(d.out + (long long)y * d.out_rs + (long long)x * COUT + nb * 32 + 4 * ch) = v;
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -682,6 +691,15 @@ static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream
     return hipGetLastError();
 }
 
+template <typename KernelT>
+static hipError_t launch_first(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(kernel, dim3((ntiles + FIRST_TPW - 1) / FIRST_TPW), dim3(256), 0, stream, d, tiles_x, ntiles);
+    return hipGetLastError();
+}
+
 hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
@@ -713,12 +731,12 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         if (d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
         switch (key) {
-        case 1032: return launch_tiled8(conv3x3_first<1, 1>, d, stream);
-        case 1064: return launch_tiled8(conv3x3_first<1, 2>, d, stream);
-        case 1128: return launch_tiled8(conv3x3_first<1, 4>, d, stream);
-        case 3032: return launch_tiled8(conv3x3_first<3, 1>, d, stream);
-        case 3064: return launch_tiled8(conv3x3_first<3, 2>, d, stream);
-        case 3128: return launch_tiled8(conv3x3_first<3, 4>, d, stream);
+        case 1032: return launch_first(conv3x3_first<1, 1>, d, stream);
+        case 1064: return launch_first(conv3x3_first<1, 2>, d, stream);
+        case 1128: return launch_first(conv3x3_first<1, 4>, d, stream);
+        case 3032: return launch_first(conv3x3_first<3, 1>, d, stream);
+        case 3064: return launch_first(conv3x3_first<3, 2>, d, stream);
+        case 3128: return launch_first(conv3x3_first<3, 4>, d, stream);
         default: return hipErrorInvalidValue;
         }
     }
