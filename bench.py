@@ -435,6 +435,23 @@ def main():
                                   "scaling": "weak"}
         except Exception as e:   # never let a side measurement break the headline line
             extras["extras_error"] = repr(e)
+    if not args.no_extras and world == 1 and workload == "scale2x_1080p":
+        # how much of ms_per_step is the shader clock the power management grants: the SAME launches on all-zero weights, biases and
+        # plane (the instruction stream has no value-dependent branch; operand bits do not toggle).  tools/power_probe.py is the long form.
+        try:
+            ms0 = w2xc._ModelSet.from_layers([(ni, no, np.zeros_like(wl), np.zeros_like(bl)) for ni, no, wl, bl in layers])
+            z_in = torch.zeros_like(d_in)
+            z_out = torch.empty_like(d_out)
+            pw = {}
+            for name in ([args.precision] if args.precision != "fp32" else ["fp32", "bf16"]):
+                oz = mk_opts(0, name)
+                runz = lambda: ms0.convert_device(z_in.data_ptr(), W * 4, W, H, z_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=oz)
+                pw[name] = round(time_steps(runz, 5, 2) / 5 * 1e3, 4)
+            extras["zero_operand_ms_per_step"] = dict(pw, note="same launches, all-zero weights / biases / plane: the time at the clock an idle "
+                                                              "datapath is granted; the gap to ms_per_step (other_precisions for bf16) is power management, not schedule")
+            del ms0, z_in, z_out
+        except Exception as e:
+            extras["zero_operand_error"] = repr(e)
 
     if rank == 0:
         in_px = in_h * in_w
