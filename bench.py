@@ -447,6 +447,14 @@ def main():
                 oz = mk_opts(0, name)
                 runz = lambda: ms0.convert_device(z_in.data_ptr(), W * 4, W, H, z_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=oz)
                 pw[name] = round(time_steps(runz, 5, 2) / 5 * 1e3, 4)
+                if name == args.precision:   # per-layer too, for the dominant kernel's fraction at the unthrottled clock (`roofline`)
+                    ozp = mk_opts(1, name)
+                    ms0.profile_reset(dev_index)
+                    for _ in range(5):
+                        ms0.convert_device(z_in.data_ptr(), W * 4, W, H, z_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=ozp)
+                    torch.cuda.synchronize()
+                    zt, zn = ms0.profile_read(dev_index)
+                    pw["layers_ms"] = [round(zt[i] / max(zn[i], 1), 4) for i in range(len(zt))]
             extras["zero_operand_ms_per_step"] = dict(pw, note="same launches, all-zero weights / biases / plane: the time at the clock an idle "
                                                               "datapath is granted; the gap to ms_per_step (other_precisions for bf16) is power management, not schedule")
             del ms0, z_in, z_out
@@ -558,6 +566,11 @@ def main():
         if host:
             out["host_to_host"] = host
         out.update(extras)
+        zl = extras.get("zero_operand_ms_per_step", {}).get("layers_ms")
+        if zl and zl[dom] > 0 and bands == 1:
+            # the dominant kernel at the clock an idle datapath gets: what the schedule alone achieves (tools/power_probe.py)
+            out["roofline"]["zero_operand_launch_ms"] = zl[dom]
+            out["roofline"]["frac_zero_operands"] = round(out["roofline"]["frac"] * dom_ms / zl[dom], 4)
         if not args.no_cpu_baseline and world == 1 and workload != "image_u8":   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(layers, nn2x(y_src), args.cpu_budget)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
