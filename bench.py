@@ -90,22 +90,23 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, cin, cout, H, W):
+def pmc_traffic(kernel, cin, cout, H, W, precision="fp32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/make_profile_summary.py).  rocprofv3 cannot
     run inside this process, so this is the profile of the SAME command -- valid only for the sources it was taken
     from: returns (bytes, note)."""
-    path = os.path.join(ROOT, "profiles", "r3_roofline.json")
+    rel = "profiles/r3_roofline.json" if precision == "fp32" else "profiles/r3_%s_roofline.json" % precision
+    path = os.path.join(ROOT, rel)
     try:
         prof = json.load(open(path))
     except Exception:
-        return None, "no committed PMC profile (profiles/r3_roofline.json)"
+        return None, "no committed PMC profile (%s)" % rel
     if prof.get("kernel_source_hash") != kernel_source_hash():
         return None, "committed PMC profile is from other kernel sources (hash %s != %s): dropped" % (prof.get("kernel_source_hash"), kernel_source_hash())
     for name, k in prof.get("kernels", {}).items():
         if kernel in name and ("<%d, %d" % (cin, cout)) in name and k.get("pixels") == (H + 2) * (W + 2):
-            return int(k["hbm_traffic_bytes"]), "profiles/r3_roofline.json (rocprofv3 --pmc, same command, same sources)"
-    return None, "no matching kernel in profiles/r3_roofline.json"
+            return int(k["hbm_traffic_bytes"]), rel + " (rocprofv3 --pmc, same command, same sources)"
+    return None, "no matching kernel in " + rel
 
 
 def cpu_baseline(layers, plane, budget_s=15.0):
@@ -508,8 +509,8 @@ def main():
             if per_layer[-1]["kernel"] == "conv3x3_last_gather":
                 per_layer[-1]["note"] = ("last layer fused: its MFMA work runs in the previous layer's epilogue (that layer's `ms` includes it, its FLOP "
                                          "figures do not); this launch only sums the partial tap planes")
-        traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W)
-                                 if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision == "fp32") else (None, "no PMC profile for this configuration"))
+        traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W, args.precision)
+                                 if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision in ("fp32", "bf16")) else (None, "no PMC profile for this configuration"))
         wl_name = {"scale2x_1080p": "scale2x_1080p (BASELINE.json configs[1])", "plane": "plane, row-sharded over ranks (BASELINE.json configs[2] at 8192x8192)",
                    "image_u8": "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU)"}[workload]
         out = {
