@@ -64,6 +64,8 @@ typedef struct w2xc_model w2xc_model;
                                  * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
 #define W2XC_KERNEL_WINOGRAD 3  /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (conv3x3_wino16), fp32 throughout */
 #define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: the round-2 Winograd kernel on v_mfma_f32_32x32x2_f32 (conv3x3_wino)        */
+#define W2XC_KERNEL_WINOGRAD4 5 /* mid layers with >= 64 output planes: Winograd F(4x4,3x3) (conv3x3_wino4), fp32 throughout: 2.25 multiplies per
+                                 * output instead of 4, rounding error ~8x F(2x2)'s (still 3-5x inside rtol 1e-4); env W2XC_WINO_KERNEL=4  */
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */

@@ -82,6 +82,7 @@ struct DevLayer {
     float *w_direct = nullptr;
     float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path, 32x32x2 kernel), packed on first use
     float *w_wino16 = nullptr;   // w2xc_wino16_pack image (fp32 Winograd path, 16x16x4 kernel), packed on first use
+    float *w_wino4 = nullptr;    // w2xc_wino4_pack image (F(4x4,3x3) kernel), packed on first use
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
@@ -177,6 +178,7 @@ struct DevCtx {
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_wino) hipFree(l.w_wino);
             if (l.w_wino16) hipFree(l.w_wino16);
+            if (l.w_wino4) hipFree(l.w_wino4);
             if (l.w_last_wino16) hipFree(l.w_last_wino16);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
@@ -407,25 +409,28 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
 // _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel unless W2XC_WINO_KERNEL=32.
-enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2 };
+//   MID_WINO4   conv3x3_wino4:  Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (round 3, opt-in: 1.78x fewer multiplies again, ~8x the rounding error)
+enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2, MID_WINO4 = 3 };
 int mid_variant(const w2xc_opts &o)
 {
     static const int env_default = [] {
         const char *e = getenv("W2XC_WINOGRAD");
         if (e && atoi(e) == 0) return (int)MID_MFMA;
         const char *k = getenv("W2XC_WINO_KERNEL");
-        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (int)MID_WINO16;
+        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (k && atoi(k) == 4) ? (int)MID_WINO4 : (int)MID_WINO16;
     }();
     switch (o.kernel) {
     case W2XC_KERNEL_MFMA: return MID_MFMA;
     case W2XC_KERNEL_WINOGRAD: return MID_WINO16;
     case W2XC_KERNEL_WINOGRAD32: return MID_WINO32;
+    case W2XC_KERNEL_WINOGRAD4: return MID_WINO4;
     default: return env_default;
     }
 }
 // the variant that really runs a (cin, cout) layer: conv3x3_wino16 needs two 32-plane groups (cout >= 64), the other Winograd kernel takes the rest
 int mid_variant_for(int midv, int cin, int cout)
 {
+    if (midv == MID_WINO4 && !w2xc_wino4_supported(cin, cout)) midv = MID_WINO16;
     if (midv == MID_WINO16 && !w2xc_wino16_supported(cin, cout)) midv = MID_WINO32;
     if (midv == MID_WINO32 && !w2xc_wino_supported(cin, cout)) midv = MID_MFMA;
     return midv;
@@ -487,10 +492,11 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     const int midv = kind == W2XC_K_MFMA ? mid_variant_for(mid_variant(o), d.cin, d.cout) : MID_MFMA;
     const bool wino = midv != MID_MFMA;
     if (wino) {
-        float *&img = midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
+        float *&img = midv == MID_WINO4 ? dl.w_wino4 : midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
         if (!img) {
-            std::vector<float> pk(w2xc_wino_packed_floats(d.cin, d.cout));
-            if (midv == MID_WINO16) w2xc_wino16_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
+            std::vector<float> pk(midv == MID_WINO4 ? (size_t)36 * d.cin * d.cout : w2xc_wino_packed_floats(d.cin, d.cout));
+            if (midv == MID_WINO4) w2xc_wino4_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
+            else if (midv == MID_WINO16) w2xc_wino16_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
             else w2xc_wino_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
             int rc = upload(pk, &img);
             if (rc) return rc;
@@ -515,7 +521,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                    : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
-                   : wino                        ? (midv == MID_WINO16 ? w2xc_launch_wino16(d, st) : w2xc_launch_wino(d, st))
+                   : wino                        ? (midv == MID_WINO4 ? w2xc_launch_wino4(d, st) : midv == MID_WINO16 ? w2xc_launch_wino16(d, st) : w2xc_launch_wino(d, st))
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -648,7 +654,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             d.out_w = w + 2 * (n - k);
             d.off_y = k == 1 ? (y0 - n - vy0) : 0;
             d.off_x = k == 1 ? -n : 0;
-            d.wino_py = (y0 - (n - k)) & 1;   // parity of this launch's first output row in the coordinates of the whole plane
+            // this launch's first output row in the coordinates of the whole plane, modulo the Winograd block height (2; conv3x3_wino4: 4)
+            d.wino_py = (y0 - (n - k)) & ((hl.nin >= 32 && hl.nout >= 32 && mid_variant_for(mid_variant(o), hl.nin, hl.nout) == MID_WINO4) ? 3 : 1);
             d.in_shift = k == 1 ? up : 0;
             const W2xcKernelKind kind = layer_kind(m, k - 1, o);
             if (kind == W2XC_K_FUSED_AWAY) {   // layer 1 inside layer 2's kernel: keep its input description for that launch
@@ -2106,7 +2113,7 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     const W2xcKernelKind k = layer_kind(m, layer, o);
     if (k == W2XC_K_MFMA) {
         const int midv = mid_variant_for(mid_variant(o), m->layers[layer].nin, m->layers[layer].nout);
-        if (midv != MID_MFMA) return midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
+        if (midv != MID_MFMA) return midv == MID_WINO4 ? "conv3x3_wino4" : midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
     }
     return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
 }

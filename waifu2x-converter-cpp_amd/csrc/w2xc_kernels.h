@@ -81,6 +81,10 @@ hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
 // the same layer on v_mfma_f32_16x16x4_f32 with 128 accumulators per wave and two workgroups per CU (w2xc_wino16.hip);
 // d.wpk = the w2xc_wino16_pack image (16 * cin * cout floats, another fragment order)
 bool w2xc_wino16_supported(int cin, int cout);
+// Winograd F(4x4,3x3) (w2xc_wino4.hip): d.wpk = the w2xc_wino4_pack image (36 * cin * cout floats), d.wino_py = first output row mod 4
+bool w2xc_wino4_supported(int cin, int cout);
+void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
+hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,
