@@ -207,6 +207,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         });
     };
 
+    // The wave that transforms the patches of stage g + 1 (in stage g) is the one with pt == (g + 1 + 2 bt) mod 4, i.e. every wave in every
+    // fourth stage, at its own phase PH = (pt - 1 - 2 bt) mod 4.  A run-time "is it my turn" around the two stage bodies joins 144 accumulators
+    // in phi nodes after every stage and the register allocator gives up (150 spilled registers); so the whole item loop exists four times,
+    // unrolled by four stages with the transforming stage fixed at compile time, and a wave picks its copy once.
+    auto run = [&](auto PH_) {
+    constexpr int PH = decltype(PH_)::value;
     // ---- prologue: raw slices 0 and 1 of the first item, U(stage 0), then V(stage 0) ----
     tile_offsets(item_of(0));
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {   // V of the first stage
+    if constexpr (PH == 3) {   // V of the first stage (stage -1 = 3 mod 4)
         const char *src = ldsb + tr_rd;
         char *dst = ldsb + tr_wr;
         static_for<0, 12>([&](auto Q) { tr_read(src, Q); });
@@ -303,10 +309,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             asm volatile("" ::: "memory");
             par = nxt;
         };
-        for (int s = 0; s < NST; s += 2) {
-            // this wave transforms stage g + 1 when (g + 1 + 2 bt) mod 4 == pt  (NST is a multiple of 4: g mod 4 = s mod 4)
-            stage(std::false_type{}, std::true_type{}, s);
-            stage(std::true_type{}, std::true_type{}, s + 1);
+#pragma unroll 1
+        for (int s = 0; s < NST; s += 4) {   // (NST is a multiple of 4: the global stage count mod 4 = s mod 4)
+            stage(std::false_type{}, std::integral_constant<bool, PH == 0>{}, s);
+            stage(std::true_type{}, std::integral_constant<bool, PH == 1>{}, s + 1);
+            stage(std::false_type{}, std::integral_constant<bool, PH == 2>{}, s + 2);
+            stage(std::true_type{}, std::integral_constant<bool, PH == 3>{}, s + 3);
         }
         {
             // ---- epilogue: Y = A^T M A, bias, LeakyReLU, NHWC stores.  C/D of the 16x16 MFMA: lane & 15 = block, register e = plane
@@ -362,6 +370,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         }
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
+    };
+    switch ((pt - 1 - 2 * bt) & 3) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
