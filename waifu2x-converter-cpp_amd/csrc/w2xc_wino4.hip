@@ -33,6 +33,18 @@
 #include <atomic>
 #include <type_traits>
 
+#ifdef W4_TIMING
+// tools/ubench/wino4_timing.hip: s_memtime stamps of waves 0 and 4 of workgroup 0 -- per stage (before the closing wait, after it, after the
+// barrier) and after every epilogue -- [wave >> 2][index]
+__device__ unsigned long long w4_stamps[2][8192];
+#define W4_STAMP(idx) do { const int i_ = (idx); if (blockIdx.x == 0 && pt == 0 && lane == 0 && i_ < 8192) w4_stamps[bt][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(idx) do { } while (0)
+#endif
+#ifndef W4_ABL
+#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no patch reads | 4 no V writes | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores
+#endif
+
 namespace {
 
 // y = B^T x for a 6-vector, in place (12 fma / add)
@@ -127,7 +139,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             const int res = rem / 9, idx = rem - res * 9;
             int col = 4 * idx + res;
             col = col < HW ? col : HW - 1;
-            lofs[jj * 512 + threadIdx.x] = (unsigned)(row | (col << 8) | ((e & 1) << 16));
+            // the two 16-byte halves of a pixel slot are SWAPPED where bit 2 of the slot's index in its residue group is set: the 8 block columns x 4
+            // channels of a patch position then hit 32 different banks (bank = 8 slot + 4 half + k)
+            lofs[jj * 512 + threadIdx.x] = (unsigned)(row | (col << 8) | ((((e & 1) ^ (idx >> 2)) & 1) << 16));
         }
     }
     unsigned voff[RPW];
@@ -177,33 +191,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 
     // ---- addressing ----
     // MFMA operands: lane-linear dwords
-    const unsigned ua0 = U_BASE + (unsigned)pt * 256u + (unsigned)lane * 4u;      // + slot * U_BYTES + xi * 1024
-    const unsigned va0 = V_BASE + (unsigned)bt * 256u + (unsigned)lane * 4u;      // + slot * V_BYTES + xi * 512
+    const unsigned ua0 = U_BASE + (unsigned)pt * 1024u + (unsigned)lane * 16u;    // + slot * U_BYTES + (xi / 4) * 4096: four xi per b128
+    const unsigned va0 = V_BASE + (unsigned)bt * 1024u + (unsigned)lane * 16u;    // + slot * V_BYTES + (xi / 4) * 2048
     // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch pixel (i, j) sits in raw slot
     // (4 (2 bt + r) + i) * 36 + (j & 3) * 9 + c + (j >> 2)
     const int tr_r = lane >> 5, tr_k = (lane >> 3) & 3, tr_c = lane & 7;
-    const unsigned tr_rd = (unsigned)(((4 * (2 * bt + tr_r)) * RSLOT + tr_c) * 32 + tr_k * 4);          // + buffer + half * 16 + immediates
-    const unsigned tr_wr = V_BASE + (unsigned)bt * 256u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 4);  // + slot * V_BYTES + xi * 512
+    const unsigned tr_rd = (unsigned)(((4 * (2 * bt + tr_r)) * RSLOT + tr_c) * 32 + tr_k * 4);          // + buffer + immediates + the swizzled half:
+    const unsigned tr_sw0 = (unsigned)(((tr_c >> 2) & 1) * 16), tr_sw1 = (unsigned)((((tr_c + 1) >> 2) & 1) * 16);   // patch columns 0..3 / 4, 5
+    const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);  // + slot * V_BYTES + (xi / 4) * 2048
 
     // the transform of one patch: reads (slots 0..11 of a stage), columns (12..17), rows + writes (18..23)
     float dd[36];
     // (indices arrive as integral constants: register arrays indexed through a run-time lambda parameter end up in scratch)
-    auto tr_read = [&](const char *src, auto Q) {   // three patch elements per call, Q = 0..11
+    auto tr_read = [&](const char *src, const char *src1, auto Q) {   // three patch elements per call, Q = 0..11; src / src1: columns 0..3 / 4, 5
         static_for<0, 3>([&](auto E3) {
             constexpr int e = decltype(Q)::value * 3 + decltype(E3)::value, i = e / 6, j = e % 6;
-            dd[e] = *reinterpret_cast<const float *>(src + i * (RSLOT * 32) + ((j & 3) * 9 + (j >> 2)) * 32);
+            if constexpr ((W4_ABL & 2) != 0) dd[e] = (float)e;
+            else dd[e] = *reinterpret_cast<const float *>((j < 4 ? src : src1) + i * (RSLOT * 32) + ((j & 3) * 9 + (j >> 2)) * 32);
         });
     };
     auto tr_col = [&](auto J) {
         constexpr int j = decltype(J)::value;
-        bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
+        if constexpr (!(W4_ABL & 1)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
     };
     auto tr_row = [&](char *dst, auto I) {
         constexpr int i = decltype(I)::value;
-        bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
-        static_for<0, 6>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            *reinterpret_cast<float *>(dst + (i * 6 + j) * 512) = dd[i * 6 + j];
+        if constexpr (!(W4_ABL & 1)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
+        // the quads of four consecutive xi that this row completes: 4 q + 3 <= 6 i + 5 and not already complete after row i - 1
+        static_for<(i == 0 ? 0 : (6 * i - 4) / 4 + 1), (6 * i + 2) / 4 + 1>([&](auto Q4) {
+            constexpr int q4 = decltype(Q4)::value;
+            if constexpr (!(W4_ABL & 4))
+                *reinterpret_cast<f32x4 *>(dst + q4 * 2048) = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
         });
     };
 
@@ -231,9 +249,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (PH == 3) {   // V of the first stage (stage -1 = 3 mod 4)
-        const char *src = ldsb + tr_rd;
+        const char *src = ldsb + tr_rd + tr_sw0, *src1 = ldsb + tr_rd + tr_sw1;
         char *dst = ldsb + tr_wr;
-        static_for<0, 12>([&](auto Q) { tr_read(src, Q); });
+        static_for<0, 12>([&](auto Q) { tr_read(src, src1, Q); });
         static_for<0, 6>([&](auto J) { tr_col(J); });
         static_for<0, 6>([&](auto I) { tr_row(dst, I); });
     }
@@ -242,6 +260,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     asm volatile("" ::: "memory");
 
     unsigned par = 0;         // parity of the global stage count: U / V buffer of the CURRENT stage
+    int stamp = 0;
+    (void)stamp;
+    W4_STAMP(stamp++);
     unsigned r_buf_cur = 0;   // raw buffer of the current stage's 8-channel slice
     for (int n = 0; n < nmy; n++) {
         const int item = item_of(n), item_n = item_of(n + 1);
@@ -260,39 +281,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             const char *va = ldsb + va0 + par * V_BYTES;
             // next stage's patches: raw slice of global stage g + 1; stage parity odd -> g + 1 even -> first half of the NEXT raw buffer
             const unsigned rb = odd ? (r_buf_cur ^ 1u) : r_buf_cur;
-            const char *src = ldsb + rb * RAW_BYTES + tr_rd + (odd ? 0 : 16);
+            const char *src = ldsb + rb * RAW_BYTES + tr_rd + ((odd ? 0u : 16u) ^ tr_sw0);
+            const char *src1 = ldsb + rb * RAW_BYTES + tr_rd + ((odd ? 0u : 16u) ^ tr_sw1);
             char *dst = ldsb + tr_wr + nxt * V_BYTES;
-            constexpr int PF = 4;
-            float a[PF], b[PF];
-#pragma unroll
-            for (int q = 0; q < PF; q++) {
-                a[q] = *reinterpret_cast<const float *>(ua + q * 1024);
-                b[q] = *reinterpret_cast<const float *>(va + q * 512);
-            }
+            // operands of four xi per ds_read_b128; the quads of the next four xi are read while these four multiply
+            f32x4 a4[2], b4[2];
+            a4[0] = *reinterpret_cast<const f32x4 *>(ua);
+            b4[0] = *reinterpret_cast<const f32x4 *>(va);
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xi % PF], b[xi % PF], acc[xi], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (xi + PF < 36) {
-                    a[xi % PF] = *reinterpret_cast<const float *>(ua + (xi + PF) * 1024);
-                    b[xi % PF] = *reinterpret_cast<const float *>(va + (xi + PF) * 512);
+                if constexpr ((xi & 3) == 0 && xi + 4 < 36) {
+                    a4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + 1) * 4096);
+                    b4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + 1) * 2048);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) & 1][xi & 3], b4[(xi >> 2) & 1][xi & 3], acc[xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 // transfers: U pieces first, raw pieces last
-                if constexpr (xi == 1 || xi == 3 || xi == 5 || xi == 7) {
+                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
                     dma_u(u_ob, u_s, nxt, ((xi - 1) >> 1) * 8 + wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (xi == 9) {
+                if constexpr (xi == 9 && !(W4_ABL & 16)) {
                     if (wave < 4) dma_u(u_ob, u_s, nxt, 32 + wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (odd && (xi == 29 || xi == 31 || xi == 33)) {
+                if constexpr (odd && (xi == 29 || xi == 31 || xi == 33) && !(W4_ABL & 32)) {
                     dma_raw((xi - 29) >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (tr) {
-                    if constexpr (xi < 12) { tr_read(src, std::integral_constant<int, xi>{}); __builtin_amdgcn_sched_barrier(0); }
+                    if constexpr (xi < 12) { tr_read(src, src1, std::integral_constant<int, xi>{}); __builtin_amdgcn_sched_barrier(0); }
                     else if constexpr (xi < 18) { tr_col(std::integral_constant<int, xi - 12>{}); __builtin_amdgcn_sched_barrier(0); }
                     else if constexpr (xi < 24) { tr_row(dst, std::integral_constant<int, xi - 18>{}); __builtin_amdgcn_sched_barrier(0); }
                 }
@@ -300,14 +319,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             if constexpr (odd) {
                 raw_advance();
                 r_buf_cur ^= 1u;
-                W2XC_WAIT_VMCNT(RPW);     // U(next stage) has landed; this stage's raw pieces (the youngest) may still fly
-            } else {
-                W2XC_WAIT_VMCNT(0);
             }
+            W4_STAMP(stamp++);
+            if constexpr (odd && !(W4_ABL & 32)) W2XC_WAIT_VMCNT(RPW);     // U(next stage) has landed; this stage's raw pieces (the youngest) may still fly
+            else W2XC_WAIT_VMCNT(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_STAMP(stamp++);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             par = nxt;
+            W4_STAMP(stamp++);
         };
 #pragma unroll 1
         for (int s = 0; s < NST; s += 4) {   // (NST is a multiple of 4: the global stage count mod 4 = s mod 4)
@@ -352,7 +373,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         y[i][3][eh] = __builtin_amdgcn_fmed3f(v3, 0.1f * v3, 3.402823466e+38f);
                     }
                 }
-                if (interior) {
+                if constexpr ((W4_ABL & 64) != 0) {
+                    if (y[0][0][0] == 12345.678f) *reinterpret_cast<f32x2 *>(obase) = y[0][0] + y[1][1] + y[2][2] + y[3][3];
+                } else if (interior) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -367,6 +390,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+            W4_STAMP(stamp++);
         }
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
@@ -387,7 +411,7 @@ bool w2xc_wino4_supported(int cin, int cout)
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
 }
 
-// wpk[64-plane block ob][stage s (4 channels)][xi = 6 i + j][plane tile pt][k][o] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k],
+// wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = 6 i + j,
 // U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
 {
@@ -407,7 +431,8 @@ void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
                         for (int i = 0; i < 6; i++)
                             for (int j = 0; j < 6; j++) {
                                 const double u = tmp[i][0] * GM[j][0] + tmp[i][1] * GM[j][1] + tmp[i][2] * GM[j][2];
-                                dst[((((size_t)ob * nst + s) * 36 + (i * 6 + j)) * 4 + pt) * 64 + k * 16 + o] = (float)u;
+                                const int xi = i * 6 + j;
+                                dst[(((((size_t)ob * nst + s) * 9 + (xi >> 2)) * 4 + pt) * 64 + k * 16 + o) * 4 + (xi & 3)] = (float)u;
                             }
                     }
 }
