@@ -207,8 +207,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         static_for<0, 3>([&](auto E3) {
             constexpr int e = decltype(Q)::value * 3 + decltype(E3)::value, i = e / 6, j = e % 6;
             if constexpr ((W4_ABL & 2) != 0) dd[e] = (float)e;
-            else dd[e] = *reinterpret_cast<const float *>((j < 4 ? src : src1) + i * (RSLOT * 32) + ((j & 3) * 9 + (j >> 2)) * 32);
+            else {
+                // inline asm: as C++ loads these reads are merged into ds_read2_b32 pairs whose 8-bit offsets need extra address registers, which the
+                // compiler hoists and then SPILLS -- and a scratch reload waits with vmcnt(0), i.e. for every transfer in flight (2000 cycles per
+                // transforming stage, measured).  The compiler does not count these reads in lgkmcnt: tr_wait() below is their wait.
+                constexpr int off = i * (RSLOT * 32) + ((j & 3) * 9 + (j >> 2)) * 32;
+                const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)(j < 4 ? src : src1);
+                float v;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+                dd[e] = v;
+            }
         });
+    };
+    auto tr_wait = [&]() {   // every patch read has returned (and the compiler sees the values as defined HERE)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]), "+v"(dd[4]), "+v"(dd[5]), "+v"(dd[6]), "+v"(dd[7]), "+v"(dd[8]), "+v"(dd[9]), "+v"(dd[10]),
+                       "+v"(dd[11]), "+v"(dd[12]), "+v"(dd[13]), "+v"(dd[14]), "+v"(dd[15]), "+v"(dd[16]), "+v"(dd[17]));
+        asm volatile(""
+                     : "+v"(dd[18]), "+v"(dd[19]), "+v"(dd[20]), "+v"(dd[21]), "+v"(dd[22]), "+v"(dd[23]), "+v"(dd[24]), "+v"(dd[25]), "+v"(dd[26]), "+v"(dd[27]),
+                       "+v"(dd[28]), "+v"(dd[29]), "+v"(dd[30]), "+v"(dd[31]), "+v"(dd[32]), "+v"(dd[33]), "+v"(dd[34]), "+v"(dd[35]));
     };
     auto tr_col = [&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -252,6 +269,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         const char *src = ldsb + tr_rd + tr_sw0, *src1 = ldsb + tr_rd + tr_sw1;
         char *dst = ldsb + tr_wr;
         static_for<0, 12>([&](auto Q) { tr_read(src, src1, Q); });
+        tr_wait();
         static_for<0, 6>([&](auto J) { tr_col(J); });
         static_for<0, 6>([&](auto I) { tr_row(dst, I); });
     }
@@ -312,7 +330,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 }
                 if constexpr (tr) {
                     if constexpr (xi < 12) { tr_read(src, src1, std::integral_constant<int, xi>{}); __builtin_amdgcn_sched_barrier(0); }
-                    else if constexpr (xi < 18) { tr_col(std::integral_constant<int, xi - 12>{}); __builtin_amdgcn_sched_barrier(0); }
+                    else if constexpr (xi < 18) {
+                        if constexpr (xi == 12) tr_wait();
+                        tr_col(std::integral_constant<int, xi - 12>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     else if constexpr (xi < 24) { tr_row(dst, std::integral_constant<int, xi - 18>{}); __builtin_amdgcn_sched_barrier(0); }
                 }
             });
