@@ -71,6 +71,7 @@ def test_kernel_choice_per_call(gpu):
         assert ms.kernel_name(1) == ms.kernel_name(1, gpu.make_opts()) and ms.kernel_name(1).startswith("conv3x3_wino")
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_MFMA)) == "conv3x3_mfma"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD32)) == "conv3x3_wino"
+    assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4)) == "conv3x3_wino4"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_DIRECT)) == "conv3x3_direct"
 
 
@@ -119,3 +120,57 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
         worst = max(worst, float(np.abs(a2 - b2).max() / np.abs(b2).max()))
     print("fused vs unfused last layer, %s: max err %.2e of the output range" % (planes, worst))
     assert worst <= 4e-6, worst
+
+
+def test_wino4_f4x4_opt_in_kernel(gpu):
+    """conv3x3_wino4 (csrc/w2xc_wino4.hip): Winograd F(4x4,3x3) on the fp32 MFMA, opt-in through w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD4
+    (layers with >= 64 output planes; the others fall back to the F(2x2) kernels).  Same fp32 arithmetic type and the same north_star
+    gate against the CPU oracle (rtol 1e-4 + atol 1e-5); its larger transform costs 4-8x the rounding error of F(2x2): measured 5e-6 of the output range
+    on the 7-layer scale2.0x topology, up to 1.9e-5 on the short test models (stated max-norm gate: 4e-5 against the oracle and the direct MFMA kernel).  Unlike the F(2x2) kernels it is NOT bit-identical
+    across bandings: an output of a 4x4 block depends -- at rounding level -- on all 36 patch values, and a block that straddles a band
+    edge sees clamped rows there instead of the plane's; banded runs are held to the same 4e-5."""
+    from oracle import oracle as orc
+    from tools import gen_model
+    w = gpu
+    o4 = lambda **kw: w.make_opts(kernel=w.KERNEL_WINOGRAD4, **kw)
+    worst_o = worst_d = worst_b = 0.0
+    for planes, seed in (([1, 32, 64, 64, 128, 128, 1], 31), ([1, 64, 128, 64, 64, 1], 32), ([1, 32, 64, 128, 128, 64, 1], 33), ([1, 32, 32, 128, 32, 1], 34),
+                         ([1, 32, 32, 64, 64, 128, 128, 1], 102)):
+        layers = gen_model.synth_layers(planes, seed)
+        ms = w._ModelSet.from_layers(layers)
+        names = [ms.kernel_name(l, o4()) for l in range(len(planes) - 1)]
+        for l in range(len(planes) - 1):
+            if planes[l] >= 32 and planes[l + 1] >= 64:
+                assert names[l] == "conv3x3_wino4", (planes, l, names)
+        oracle = orc.Oracle(layers)
+        for (h, wd) in ((37, 61), (16, 32), (130, 70), (17, 33), (1, 1), (64, 200)):
+            x = np.random.default_rng(h * 7 + wd).random((h, wd), dtype=np.float32)
+            a = ms.convert(x, opts=o4())
+            want = oracle.convert(x, njob=8)
+            d = ms.convert(x, opts=w.make_opts(kernel=w.KERNEL_MFMA))
+            assert np.allclose(a, want, rtol=1e-4, atol=1e-5), (planes, h, wd)
+            rng = float(np.abs(want).max())
+            worst_o = max(worst_o, float(np.abs(a - want).max()) / rng)
+            worst_d = max(worst_d, float(np.abs(a - d).max()) / rng)
+            for band in (1, 5, 16, 64):
+                worst_b = max(worst_b, float(np.abs(a - ms.convert(x, opts=o4(band_rows=band))).max()) / rng)
+            a2 = ms.convert_nn2x(x, opts=o4())
+            worst_d = max(worst_d, float(np.abs(a2 - ms.convert_nn2x(x, opts=w.make_opts(kernel=w.KERNEL_MFMA))).max()) / float(np.abs(a2).max()))
+        l = next(i for i in range(len(planes) - 1) if planes[i] >= 32 and planes[i + 1] >= 64)
+        xin = np.random.default_rng(6).random((planes[l], 21, 45), dtype=np.float32)
+        f4, fd = ms.filter(l, xin, opts=o4()), ms.filter(l, xin, opts=w.make_opts(kernel=w.KERNEL_MFMA))   # Model::filter: same-size conv
+        worst_d = max(worst_d, float(np.abs(f4 - fd).max() / np.abs(fd).max()))
+    print("conv3x3_wino4: max err %.2e of the output range vs the oracle, %.2e vs conv3x3_mfma2, %.2e between bandings" % (worst_o, worst_d, worst_b))
+    assert worst_o <= 4e-5 and worst_d <= 4e-5 and worst_b <= 4e-5, (worst_o, worst_d, worst_b)
+
+
+def test_wino4_whole_frame_vs_direct_mfma(gpu):
+    """every pixel of the 2160x3840 plane of BASELINE configs[1] (strip walk, XCD chunks, all tile borders): F(4x4) vs the direct MFMA kernel"""
+    from tools import gen_model
+    ms = gpu._ModelSet.from_layers(gen_model.synth_layers(seed=102))
+    x = np.random.default_rng(2).random((2160, 3840), dtype=np.float32)
+    a = ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4))
+    d = ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_MFMA))
+    err = float(np.abs(a - d).max() / np.abs(d).max())
+    print("conv3x3_wino4 whole frame vs conv3x3_mfma2: %.2e of the output range" % err)
+    assert np.isfinite(a).all() and err <= 2e-5, err
