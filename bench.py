@@ -400,6 +400,15 @@ def main():
                     other[name] = {"ms_per_step": round(t, 3), "Mpix_s": round(in_h * in_w / t / 1e3, 2),
                                    "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
                 extras["other_precisions"] = other
+                # the opt-in Winograd F(4x4,3x3) kernel on the same plane (w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD4; fp32 throughout; last layer unfused)
+                o4 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, band_rows=args.band_rows, kernel=w2xc.KERNEL_WINOGRAD4)
+                run4 = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o4)
+                t4 = time_steps(run4, 5, 2) / 5 * 1e3
+                extras["other_kernels"] = {"winograd_f4x4 (conv3x3_wino4, opt-in)": {
+                    "ms_per_step": round(t4, 3), "Mpix_s": round(in_h * in_w / t4 / 1e3, 2),
+                    "max_abs_diff_vs_default_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng)),
+                    "note": "2.25 multiplies per output instead of F(2x2)'s 4; ~2-4x its rounding error, still inside rtol 1e-4; results depend on "
+                            "the banding at rounding level (DESIGN 3): not the default"}}
                 # BASELINE.json configs[2] on ONE GPU (what N > 1 shards): 8192x8192 frame, host -> host and resident
                 del ref
                 yb = synth_luma(seed=2, h=8192, w=8192)
