@@ -9,21 +9,29 @@
 //     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 //   The larger transform costs accuracy: measured 6e-6 .. 1e-5 of the output range against the fp64 truth through the 7-layer net
-//   (F(2x2): 1.1-1.6e-6, the direct fp32 sum 0.9-1.5e-6), i.e. a fifth to a third of the rtol 1e-4 + atol 1e-5 gate.
+//   (F(2x2): 1.1-1.6e-6, the direct fp32 sum 0.9-1.5e-6), i.e. a fifth to a third of the rtol 1e-4 + atol 1e-5 gate on image-range planes -- and
+//   element-wise misses of that gate on near-zero outputs of standard-normal test planes: OPT-IN (W2XC_KERNEL_WINOGRAD4), DESIGN.md 3 / 4.
 //
 //   Work item  16 rows x 32 pixels of output (4 x 8 blocks of 4x4) x 64 output planes.  8 waves: wave (bt, pt) owns block tile bt
 //              (16 blocks = block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
-//   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave (1152 cycles), operands straight from LDS:
-//              A = U[xi][pt] (lane = 16 k + o), B = V[xi][bt] (lane = 16 k + t): one ds_read_b32 each, 256 contiguous bytes per wave.
+//   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave (1152 cycles), BOTH operands from LDS in fragment order
+//              [xi / 4][tile][lane][xi % 4]: one ds_read_b128 per four xi and operand (A = U, lane = 16 k + o; B = V, lane = 16 k + t).
 //   V          is computed ONCE per (block, channel) and shared by the four plane-tile waves through LDS: in stage g the waves with
 //              pt == (g + 1 + 2 bt) mod 4 transform the patches of stage g + 1 (one 6x6 patch per lane: 36 ds_read_b32 from the raw tile,
-//              144 fma / add, 36 ds_write_b32 in fragment order), interleaved with their own MFMAs.
+//              144 fma / add, 9 ds_write_b128), interleaved with their own MFMAs.  The item loop exists FOUR times (one copy per
+//              transformer phase, unrolled by four stages): see `run` below.
 //   LDS        raw[2] x 21 KiB: the 18 x 34 pixel halo tile of an 8-channel slice (two stages), 32 bytes per pixel slot, a row's pixels
-//              ordered by column mod 4 (9 slots each) so that the 8 block columns of a patch position are consecutive slots;
-//              U[2] x 36 KiB: weights of (plane block, stage) in fragment order [xi][pt][k][o]; V[2] x 18 KiB: [xi][bt][k][t]; bias.
+//              ordered by column mod 4 (9 slots each) so that the 8 block columns of a patch position are consecutive slots, the two
+//              16-byte halves of a slot swapped where bit 2 of its index is set (conflict-free patch reads);
+//              U[2] x 36 KiB + V[2] x 18 KiB + 6 KiB of per-lane transfer coordinates + bias = 155 KiB.
 //   Transfers  LDS-DMA, SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead), every second stage 21 raw pieces (the
 //              slice two slices ahead); U first, raw pieces last: the closing counted vmcnt leaves the raw pieces in flight.
-//   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4).
+//   Epilogue   Y = A^T M A per output-row pair, bias, LeakyReLU, 16-byte NHWC stores.
+//   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4): interior blocks do not
+//              depend on the banding, blocks that straddle a band edge do at rounding level (every output of a block sees all 36 patch
+//              values; F(2x2) outputs do not) -- one of the two reasons this kernel is opt-in.
+// Measured (round 3, 2160x3840): 128->128 7.1 ms (conv3x3_wino16 8.8), frame 16.4 ms against 19.6; 0.52-0.55 of the fp32 MFMA rate on the multiplies
+// it issues -- what the rest is: DESIGN.md 3, profiles/r3_sweeps.log block 20.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
