@@ -7,6 +7,7 @@ cd $GRAFT_REPO_ROOT
 python tools/make_profile_summary.py gpurun_out/prof_r3 gpurun_out/r3 fp32 2>&1 | tail -3
 python tools/make_profile_summary.py gpurun_out/prof_r3_bf16 gpurun_out/r3_bf16 bf16 2>&1 | tail -3
 cp gpurun_out/r3_roofline.json profiles/r3_roofline.json
+cp gpurun_out/r3_bf16_roofline.json profiles/r3_bf16_roofline.json
 python bench.py > gpurun_out/r3_bench_fp32.json 2> gpurun_out/bench_fp32.err; tail -c 900 gpurun_out/r3_bench_fp32.json
 python bench.py --precision bf16 --no-cpu-baseline > gpurun_out/r3_bench_bf16.json 2> gpurun_out/bench_bf16.err; tail -c 700 gpurun_out/r3_bench_bf16.json
 python tools/run_configs.py > gpurun_out/r3_configs.json 2> gpurun_out/configs.err; tail -c 600 gpurun_out/r3_configs.json
