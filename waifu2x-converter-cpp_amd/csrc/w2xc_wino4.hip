@@ -4,13 +4,13 @@
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 4x4 output block and 6x6 input patch: 36 positions xi of the transformed domain =
 //   36 independent GEMMs  M_xi[o][t] = sum_c U_xi[o][c] V_xi[c][t]  (o = output plane, t = block, c = input plane) -- 36 multiplies
 //   for 16 outputs, 2.25 per output against 4 of F(2x2,3x3) (conv3x3_wino16) and 9 of the direct sum.  fp32 throughout; the
-//   matrices are Lavin & Gray's (interpolation points 0, +-1, +-2, inf):
-//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-//     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-//   The larger transform costs accuracy: measured 6e-6 .. 1e-5 of the output range against the fp64 truth through the 7-layer net
-//   (F(2x2): 1.1-1.6e-6, the direct fp32 sum 0.9-1.5e-6), i.e. a fifth to a third of the rtol 1e-4 + atol 1e-5 gate on image-range planes -- and
-//   element-wise misses of that gate on near-zero outputs of standard-normal test planes: OPT-IN (W2XC_KERNEL_WINOGRAD4), DESIGN.md 3 / 4.
+//   matrices are the Cook-Toom construction on the interpolation points 0, +-1/2, +-3/2, inf (every entry of B^T and A^T a dyadic rational, exact in fp32):
+//     B^T = [9/16 0 -5/2 0 1 0; 0 -9/8 -9/4 1/2 1 0; 0 9/8 -9/4 -1/2 1 0; 0 -3/8 -1/4 3/2 1 0; 0 3/8 -1/4 -3/2 1 0; 0 9/16 0 -5/2 0 1]
+//     G   = [16/9 0 0; -1 -1/2 -1/4; -1 1/2 -1/4; 1/9 1/6 1/4; 1/9 -1/6 1/4; 0 0 1]
+//     A^T = [1 1 1 1 1 0; 0 1/2 -1/2 3/2 -3/2 0; 0 1/4 1/4 9/4 9/4 0; 0 1/8 -1/8 27/8 -27/8 1]
+//   The points matter: Lavin & Gray's 0, +-1, +-2 (entries up to 5 and 8) cost 3x the rounding error -- 9.5e-6 of the output range against the fp64
+//   truth through the 7-layer net and element-wise misses of the rtol 1e-4 + atol 1e-5 gate on near-zero outputs (measured on the GPU: 2.7e-5 abs at
+//   |out| <= 5.7); these give 3.0e-6 (F(2x2): 1.1e-6, the direct fp32 sum 0.9e-6) at the same operation count (tools/winograd_points.py).
 //
 //   Work item  16 rows x 32 pixels of output (4 x 8 blocks of 4x4) x 64 output planes.  8 waves: wave (bt, pt) owns block tile bt
 //              (16 blocks = block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
@@ -55,29 +55,29 @@ __device__ unsigned long long w4_stamps[2][8192];
 
 namespace {
 
-// y = B^T x for a 6-vector, in place (12 fma / add)
+// y = B^T x for a 6-vector, in place (14 fma / mul / add)
 static __device__ __forceinline__ void bt6(float &x0, float &x1, float &x2, float &x3, float &x4, float &x5)
 {
-    const float y0 = __builtin_fmaf(-5.0f, x2, __builtin_fmaf(4.0f, x0, x4));
-    const float p = __builtin_fmaf(-4.0f, x2, x4), q = __builtin_fmaf(-4.0f, x1, x3);
-    const float u = x4 - x2, v = x3 - x1;
-    const float y5 = __builtin_fmaf(-5.0f, x3, __builtin_fmaf(4.0f, x1, x5));
+    const float y0 = __builtin_fmaf(-2.5f, x2, __builtin_fmaf(0.5625f, x0, x4));
+    const float p = __builtin_fmaf(-2.25f, x2, x4), q = __builtin_fmaf(-1.125f, x1, 0.5f * x3);
+    const float u = __builtin_fmaf(-0.25f, x2, x4), v = __builtin_fmaf(-0.375f, x1, 1.5f * x3);
+    const float y5 = __builtin_fmaf(-2.5f, x3, __builtin_fmaf(0.5625f, x1, x5));
     x0 = y0;
     x1 = p + q;
     x2 = p - q;
-    x3 = __builtin_fmaf(2.0f, v, u);
-    x4 = __builtin_fmaf(-2.0f, v, u);
+    x3 = u + v;
+    x4 = u - v;
     x5 = y5;
 }
 
-// y = A^T m for a 6-vector (10 fma / add)
+// y = A^T m for a 6-vector (12 fma / mul / add)
 static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2, float &y3)
 {
     const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y0 = m0 + s1 + s2;
-    y1 = __builtin_fmaf(2.0f, d2, d1);
-    y2 = __builtin_fmaf(4.0f, s2, s1);
-    y3 = __builtin_fmaf(8.0f, d2, d1) + m5;
+    y1 = __builtin_fmaf(1.5f, d2, 0.5f * d1);
+    y2 = __builtin_fmaf(2.25f, s2, 0.25f * s1);
+    y3 = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.125f, d1, m5));
 }
 
 }   // namespace
@@ -395,10 +395,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                         if (rp == 0) {
                             tm[0][j][e] = m0 + s1 + s2;
-                            tm[1][j][e] = __builtin_fmaf(2.0f, d2, d1);
+                            tm[1][j][e] = __builtin_fmaf(1.5f, d2, 0.5f * d1);
                         } else {
-                            tm[0][j][e] = __builtin_fmaf(4.0f, s2, s1);
-                            tm[1][j][e] = __builtin_fmaf(8.0f, d2, d1) + m5;
+                            tm[0][j][e] = __builtin_fmaf(2.25f, s2, 0.25f * s1);
+                            tm[1][j][e] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.125f, d1, m5));
                         }
                     }
 #pragma unroll
@@ -453,8 +453,8 @@ bool w2xc_wino4_supported(int cin, int cout)
 // U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
 {
-    static const double GM[6][3] = {{0.25, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    static const double GM[6][3] = {{16.0 / 9, 0, 0},     {-1.0, -0.5, -0.25},        {-1.0, 0.5, -0.25},
+                                    {1.0 / 9, 1.0 / 6, 0.25}, {1.0 / 9, -1.0 / 6, 0.25}, {0, 0, 1}};
     const int nst = cin / 4, nob = cout / 64;
     for (int ob = 0; ob < nob; ob++)
         for (int s = 0; s < nst; s++)
