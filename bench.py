@@ -518,7 +518,7 @@ def main():
             if per_layer[-1]["kernel"] == "conv3x3_last_gather":
                 per_layer[-1]["note"] = ("last layer fused: its MFMA work runs in the previous layer's epilogue (that layer's `ms` includes it, its FLOP "
                                          "figures do not); this launch only sums the partial tap planes")
-        traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom), ms.planes(dom)[0], ms.planes(dom)[1], H, W, args.precision)
+        traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom, opts), ms.planes(dom)[0], ms.planes(dom)[1], H, W, args.precision)
                                  if (dom == n_layers - 2 and bands == 1 and not sharded and args.precision in ("fp32", "bf16")) else (None, "no PMC profile for this configuration"))
         wl_name = {"scale2x_1080p": "scale2x_1080p (BASELINE.json configs[1])", "plane": "plane, row-sharded over ranks (BASELINE.json configs[2] at 8192x8192)",
                    "image_u8": "image_u8 (N2: u8 RGB in -> u8 2x RGB out, colour + bicubic U/V on the GPU)"}[workload]
