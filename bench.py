@@ -407,7 +407,7 @@ def main():
                 extras["other_kernels"] = {"winograd_f4x4 (conv3x3_wino4, opt-in)": {
                     "ms_per_step": round(t4, 3), "Mpix_s": round(in_h * in_w / t4 / 1e3, 2),
                     "max_abs_diff_vs_default_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng)),
-                    "note": "2.25 multiplies per output instead of F(2x2)'s 4; ~2-4x its rounding error, still inside rtol 1e-4; results depend on "
+                    "note": "2.25 multiplies per output instead of F(2x2)'s 4; ~1.5x its rounding error (inside rtol 1e-4 on image-range planes); results depend on "
                             "the banding at rounding level (DESIGN 3): not the default"}}
                 # BASELINE.json configs[2] on ONE GPU (what N > 1 shards): 8192x8192 frame, host -> host and resident
                 del ref
