@@ -171,6 +171,8 @@ def test_wino4_whole_frame_vs_direct_mfma(gpu):
     ms = gpu._ModelSet.from_layers(gen_model.synth_layers(seed=102))
     x = np.random.default_rng(2).random((2160, 3840), dtype=np.float32)
     a = ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4))
+    for _ in range(3):   # the counted-vmcnt / barrier protocol is deterministic: a transfer landing late or a buffer overwritten early shows up as differing tiles
+        assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4)))
     d = ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_MFMA))
     err = float(np.abs(a - d).max() / np.abs(d).max())
     print("conv3x3_wino4 whole frame vs conv3x3_mfma2: %.2e of the output range" % err)
