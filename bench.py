@@ -31,9 +31,9 @@ Extra objects on the JSON line:
                pixel) / its average duration from hipEvents recorded on the launch stream (w2xc_opts.profile)
                in a second pass of the same K steps right after the timed region (so the events are not inside
                `value`'s region; `ms_per_step_profiled` shows they cost nothing), vs the 157.3 TFLOP/s fp32 MFMA peak.
-               That layer runs a Winograd kernel (conv3x3_wino16 / conv3x3_wino, F(2x2,3x3): 16 instead of 36 multiplies
-               per plane pair and 2x2 block, all fp32).  `achieved` / `frac` are what the MFMA pipe really does: the
-               FLOPs the kernel ISSUES (16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
+               That layer runs a Winograd kernel (conv3x3_wino4, F(4x4,3x3): 36 instead of 144 multiplies per plane pair and
+               4x4 block; conv3x3_wino16 / conv3x3_wino, F(2x2,3x3): 16 instead of 36 per 2x2 block; all fp32).  `achieved` / `frac`
+               are what the MFMA pipe really does: the FLOPs the kernel ISSUES (1/4 resp. 16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
                reproducible from profiles/r3_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
                time) is carried beside it as `algorithmic_tflops` / `algorithmic_speedup_vs_direct_roofline` (> 1 means
                faster than ANY direct convolution could be on this MFMA).  w2xc_opts.kernel = W2XC_KERNEL_MFMA (or
@@ -293,7 +293,7 @@ def main():
         step, step_prof = mk_step(0), mk_step(1)
     elif sharded:
         # one plane, rank r owns output rows [ra, rb); its input view (rows + n_layers halo of the 2x plane) is resident in HBM
-        y0, y1 = w2xc.shard_view(H, ra, rb, n_layers)
+        y0, y1 = w2xc.shard_view(H, ra, rb, 4 * n_layers)   # the wide halo: the default F(4x4) kernel's banding-invariant geometry (shards stitch bit-identically)
         view = nn2x(y_src[y0 // 2:(y1 + 1) // 2])[y0 - 2 * (y0 // 2):][:y1 - y0]
         d_in = torch.from_numpy(np.ascontiguousarray(view)).cuda()
         del view
@@ -335,7 +335,7 @@ def main():
         def host_leg(precision, pinned, steps):
             """rows [ra, rb) of the 2x conversion of y_src: host source plane in (nearest-2x fused into layer 1, so the 4x
             larger plane never crosses PCIe, main.cpp:132-148), host output rows out.  Per-call wall times."""
-            sy0, sy1 = max(0, ra - n_layers) // 2, (min(H, rb + n_layers) + 1) // 2
+            sy0, sy1 = max(0, ra - 4 * n_layers) // 2, (min(H, rb + 4 * n_layers) + 1) // 2   # the wide halo, as for the resident shard above
             if pinned:
                 src = torch.from_numpy(y_src[sy0:sy1]).pin_memory()
                 dst = torch.empty((rb - ra, W), dtype=torch.float32).pin_memory()
@@ -400,15 +400,14 @@ def main():
                     other[name] = {"ms_per_step": round(t, 3), "Mpix_s": round(in_h * in_w / t / 1e3, 2),
                                    "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
                 extras["other_precisions"] = other
-                # the opt-in Winograd F(4x4,3x3) kernel on the same plane (w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD4; fp32 throughout; last layer unfused)
-                o4 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, band_rows=args.band_rows, kernel=w2xc.KERNEL_WINOGRAD4)
+                # the F(2x2,3x3) kernel of round 3's first half on the same plane (w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD: conv3x3_wino16, last layer fused)
+                o4 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, band_rows=args.band_rows, kernel=w2xc.KERNEL_WINOGRAD)
                 run4 = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o4)
                 t4 = time_steps(run4, 5, 2) / 5 * 1e3
-                extras["other_kernels"] = {"winograd_f4x4 (conv3x3_wino4, opt-in)": {
+                extras["other_kernels"] = {"winograd_f2x2 (conv3x3_wino16, w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD)": {
                     "ms_per_step": round(t4, 3), "Mpix_s": round(in_h * in_w / t4 / 1e3, 2),
                     "max_abs_diff_vs_default_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng)),
-                    "note": "2.25 multiplies per output instead of F(2x2)'s 4; ~1.5x its rounding error (inside rtol 1e-4 on image-range planes); results depend on "
-                            "the banding at rounding level (DESIGN 3): not the default"}}
+                    "note": "4 multiplies per output where the default F(4x4,3x3) kernel does 2.25; the last layer rides in its epilogue"}}
                 # BASELINE.json configs[2] on ONE GPU (what N > 1 shards): 8192x8192 frame, host -> host and resident
                 del ref
                 yb = synth_luma(seed=2, h=8192, w=8192)
@@ -494,8 +493,9 @@ def main():
         # split modes: every algorithmic multiply-add is 3 (bf16x2, fp16x2) or 6 (bf16x3) 16-bit MFMA products
         products = {"fp32": 1, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "fp16x2": 3}[args.precision]
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
-        def issued(l):   # fraction of a layer's algorithmic multiplies its kernel issues (Winograd F(2x2,3x3): 16 of 36)
-            return 16.0 / 36.0 if "wino" in ms.kernel_name(l, opts) else 1.0
+        def issued(l):   # fraction of a layer's algorithmic multiplies its kernel issues (Winograd F(2x2,3x3): 16 of 36; F(4x4,3x3): 36 of 144)
+            name = ms.kernel_name(l, opts)
+            return 0.25 if name == "conv3x3_wino4" else 16.0 / 36.0 if "wino" in name else 1.0
         algorithmic = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # a fused last layer's MFMAs are issued by the dominant kernel too (taps-as-rows on 16x16x4 tiles: 16 rows x cin per pixel, 9 of them useful)
         fused_last = dom + 1 == n_layers - 1 and ms.kernel_name(dom + 1, opts) == "conv3x3_last_gather" and args.precision == "fp32"
@@ -564,7 +564,8 @@ def main():
                          "algorithmic_flops_per_launch": dom_flops,
                          "algorithmic_tflops": round(algorithmic, 3),
                          "algorithmic_speedup_vs_direct_roofline": round(algorithmic / peak, 4),
-                         "note": ("Winograd F(2x2,3x3) issues 16/36 of the algorithmic multiplies: `achieved` / `frac` are the MFMA pipe's own rate (issued "
+                         "note": (("Winograd F(4x4,3x3) issues 36/144" if issued(dom) == 0.25 else "Winograd F(2x2,3x3) issues 16/36") +
+                                  " of the algorithmic multiplies: `achieved` / `frac` are the MFMA pipe's own rate (issued "
                                   "FLOPs / time / peak); `algorithmic_tflops` is SURVEY 8(d)'s FLOPs over the same time -- above the peak, i.e. faster than a "
                                   "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs") +
                                  ("; the launch also issues the fused last layer's MFMAs (`fused_last_layer_flops_per_launch`, +3 %), counted in `achieved` but "

@@ -7,9 +7,9 @@ import os
 import re
 
 # fp32 kernel of the 32- / 64- / 128-plane layers under W2XC_KERNEL_AUTO: the process default, read once from the environment
-# (w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32 picks per call)
+# (w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32 / _WINOGRAD4 picks per call)
 MID_128 = ("conv3x3_mfma" if os.environ.get("W2XC_WINOGRAD", "1") == "0"
-           else "conv3x3_wino" if os.environ.get("W2XC_WINO_KERNEL", "16") == "32" else "conv3x3_wino16")
+           else {"32": "conv3x3_wino", "16": "conv3x3_wino16"}.get(os.environ.get("W2XC_WINO_KERNEL", "4"), "conv3x3_wino4"))
 
 import numpy as np
 import pytest
@@ -197,7 +197,9 @@ def test_argument_validation(w2xc, noise1_layers):
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_last"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last_gather"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_MFMA)) == "conv3x3_last"   # (no fused epilogue in that kernel)
-    assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino16 leaves 32 OUTPUT planes to conv3x3_wino)
+    assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino4 / conv3x3_wino16 leave 32 OUTPUT planes to conv3x3_wino)
+    assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_wino4"
+    assert ms.kernel_name(5, w2xc.make_opts(fusion=w2xc.FUSION_ON)) == ("conv3x3_wino16" if MID_128.startswith("conv3x3_wino") and MID_128 != "conv3x3_wino" else MID_128)   # an explicit fusion request is served by the kernel that has that epilogue
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma"          # per-call choice of the mid-layer kernel
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_wino16"
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD32)) == "conv3x3_wino"

@@ -214,7 +214,7 @@ def test_row_band_entry_point(gpu, scale_layers, parts, precision):
     o = gpu.make_opts(device=0, precision=precision)
     for p in range(parts):
         ra, rb = gpu.shard_rows(h, parts, p)
-        y0, y1 = gpu.shard_view(h, ra, rb, ms.n_layers)
+        y0, y1 = gpu.shard_view(h, ra, rb, 4 * ms.n_layers)   # the wide halo: bit-identity with the whole-plane call under the default F(4x4) kernel
         view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
         ms.convert_rows_device(view.data_ptr(), w * 4, y1 - y0, y0, w, h, ra, rb, out[ra:].data_ptr(), w * 4,
                                stream=st.cuda_stream, opts=o)

@@ -44,7 +44,7 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         sub = "conv3x3_last_gather"   # fp32: the last layer inside conv3x3_wino16's epilogue + this gather (w2xc_opts.fusion)
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
     if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino16<CIN, COUT, 0> / conv3x3_wino<CIN, COUT>)
-        for sub in ("conv3x3_wino16<%d, %d," % (cin, cout), "conv3x3_wino<%d, %d>" % (cin, cout)):
+        for sub in ("conv3x3_wino4<%d, %d>" % (cin, cout), "conv3x3_wino16<%d, %d," % (cin, cout), "conv3x3_wino<%d, %d>" % (cin, cout)):
             names = [n for n in stats if sub in n]
             if names:
                 break
@@ -69,9 +69,10 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     if T > 0 and k == NL - 1 and any("conv3x3_last_gather" in n for n in stats):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     wino = "conv3x3_wino" in name
-    e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": 16.0 / 36.0 if wino else 1.0,
+    issued = 0.25 if "conv3x3_wino4" in name else 16.0 / 36.0 if wino else 1.0   # F(4x4,3x3): 36 of 144 multiplies; F(2x2,3x3): 16 of 36
+    e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": issued,
          "algorithmic_flops": 18 * cin * cout * px, "algorithmic_tflops": 18 * cin * cout * px / avg_ns / 1e3,
-         "tflops": 18 * cin * cout * px / avg_ns / 1e3 * (16.0 / 36.0 if wino else 1.0),   # FLOPs the kernel issues / time
+         "tflops": 18 * cin * cout * px / avg_ns / 1e3 * issued,   # FLOPs the kernel issues / time
          "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
          "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}

@@ -472,7 +472,10 @@ def shard_rows(plane_h, n_parts, part):
 
 def shard_view(plane_h, row_begin, row_end, n_layers):
     """Input rows [y0, y1) a shard needs: its rows plus an n_layers halo, clipped to the plane
-    (the 2*nModel overlap of the reference's block split, convertRoutine.cpp:100-131)."""
+    (the 2*nModel overlap of the reference's block split, convertRoutine.cpp:100-131).  This is the MINIMUM the row entry points accept;
+    a shard that is to stitch BIT-identically with the whole-plane call passes the wide halo -- shard_view(h, ra, rb, 4 * n_layers) -- which the
+    default F(4x4) mid-layer kernel needs for its banding-invariant geometry (on the minimum view W2XC_KERNEL_AUTO runs the F(2x2) kernels:
+    same tolerance, another rounding)."""
     return max(0, row_begin - n_layers), min(plane_h, row_end + n_layers)
 
 

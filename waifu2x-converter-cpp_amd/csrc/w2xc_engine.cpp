@@ -270,6 +270,8 @@ int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o);
+int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o);
+bool uses_wino4(const w2xc_model *m, const w2xc_opts &o);
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
@@ -408,8 +410,10 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 //   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD (round 3; 64 / 128 output planes)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
-// _WINOGRAD32); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0, the 16x16x4 kernel unless W2XC_WINO_KERNEL=32.
-//   MID_WINO4   conv3x3_wino4:  Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (round 3, opt-in: 1.78x fewer multiplies again, ~8x the rounding error)
+// _WINOGRAD32 / _WINOGRAD4); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0 -- conv3x3_wino4 (F(4x4,3x3)) where it applies
+// (>= 64 output planes) unless W2XC_WINO_KERNEL=16 (conv3x3_wino16) or =32 (conv3x3_wino).
+//   MID_WINO4   conv3x3_wino4:  Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (round 3, the default: 1.78x fewer multiplies again, ~1.3x the rounding error of
+//               F(2x2); needs the four-rows-per-layer band geometry of run_rows to stay banding-invariant)
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2, MID_WINO4 = 3 };
 int mid_variant(const w2xc_opts &o)
 {
@@ -417,7 +421,7 @@ int mid_variant(const w2xc_opts &o)
         const char *e = getenv("W2XC_WINOGRAD");
         if (e && atoi(e) == 0) return (int)MID_MFMA;
         const char *k = getenv("W2XC_WINO_KERNEL");
-        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (k && atoi(k) == 4) ? (int)MID_WINO4 : (int)MID_WINO16;
+        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (k && atoi(k) == 16) ? (int)MID_WINO16 : (int)MID_WINO4;
     }();
     switch (o.kernel) {
     case W2XC_KERNEL_MFMA: return MID_MFMA;
@@ -436,6 +440,28 @@ int mid_variant_for(int midv, int cin, int cout)
     return midv;
 }
 
+// the variant mid layer l really runs with these options.  An EXPLICIT request for the fused last layer (w2xc_opts.fusion = W2XC_FUSION_ON) is served by
+// conv3x3_wino16, the kernel that has that epilogue, whatever the process default for the mid layers is.
+int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o)
+{
+    const HostLayer &p = m->layers[l];
+    int midv = mid_variant(o);
+    if (midv == MID_WINO4 && o.kernel == W2XC_KERNEL_AUTO && o.fusion == W2XC_FUSION_ON && l == (int)m->layers.size() - 2) midv = MID_WINO16;
+    return mid_variant_for(midv, p.nin, p.nout);
+}
+// does any layer of the fp32 path run conv3x3_wino4 (F(4x4,3x3))?  Its 4x4 blocks make results depend on where a band's per-layer regions end,
+// unless they end on block boundaries: run_rows then computes FOUR rows of halo per layer instead of one (and needs 4 n halo rows in its view).
+bool uses_wino4(const w2xc_model *m, const w2xc_opts &o)
+{
+    if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || o.kernel == W2XC_KERNEL_DIRECT) return false;
+    for (int l = 0; l < (int)m->layers.size(); l++)
+        if (w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout) == W2XC_K_MFMA && layer_mid_variant(m, l, o) == MID_WINO4) return true;
+    return false;
+}
+// halo rows (per side, clipped to the plane) the SOURCE view of rows [ra, rb) should hold: n = one per layer; 4 n for the banding-invariant
+// geometry of conv3x3_wino4 (per-layer regions rounded out to multiples of 4 rows and grown by 4 rows per layer)
+int src_halo_rows(const w2xc_model *m, const w2xc_opts &o) { return (int)m->layers.size() * (uses_wino4(m, o) ? 4 : 1); }
+
 // fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
 // the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
 // w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
@@ -447,7 +473,7 @@ bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
     if (o.fusion == W2XC_FUSION_OFF || (o.fusion != W2XC_FUSION_ON && !env_default)) return false;
     const HostLayer &p = m->layers[n - 2], &q = m->layers[n - 1];
     if (q.nout != 1 || q.nin != p.nout || w2xc_pick_kernel(q.nin, 1) != W2XC_K_LAST || w2xc_pick_kernel(p.nin, p.nout) != W2XC_K_MFMA) return false;
-    return mid_variant_for(mid_variant(o), p.nin, p.nout) == MID_WINO16;
+    return layer_mid_variant(m, n - 2, o) == MID_WINO16;
 }
 
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
@@ -489,7 +515,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
-    const int midv = kind == W2XC_K_MFMA ? mid_variant_for(mid_variant(o), d.cin, d.cout) : MID_MFMA;
+    const int midv = kind == W2XC_K_MFMA ? layer_mid_variant(m, l, o) : MID_MFMA;
     const bool wino = midv != MID_MFMA;
     if (wino) {
         float *&img = midv == MID_WINO4 ? dl.w_wino4 : midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
@@ -551,12 +577,32 @@ struct BandHooks {
 // Multi-plane form (w2xc_convert_planes_*): n_in planar input planes `in_cs` floats apart, ALL planes of the
 // last layer written planar `out_cs` floats apart.  n_in == 1 && out_cs == 0 is convertWithModels proper,
 // which returns only outputPlanes[0] (convertRoutine.cpp:78).
+// plane_h = rows of the whole plane (the units of vh / vy0 / ra / rb), 0 = unknown.  With it, and a view that holds 4 n halo rows, the
+// layers run on the banding-invariant geometry conv3x3_wino4 needs (below); without, W2XC_KERNEL_AUTO falls back to the F(2x2) kernels.
 int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,
-             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o, int up = 0, int n_in = 1,
-             long long in_cs = 0, long long out_cs = 0, const BandHooks *hk = nullptr)
+             float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o_in, int up = 0, int n_in = 1,
+             long long in_cs = 0, long long out_cs = 0, const BandHooks *hk = nullptr, int plane_h = 0)
 {
     const int n = (int)m->layers.size();
     if (n == 0) return fail(W2XC_ERR_ARG, "model has no layers");
+    // conv3x3_wino4 (F(4x4,3x3)): an output of a 4x4 block depends, at rounding level, on all 36 patch values, so a block cut by the edge of a
+    // band's region (clamped rows instead of the plane's) would make results depend on the banding.  HL = 4: every layer k < n computes the rows
+    //     [floor4(y0) - 4 (n - k), ceil4(y1) + 4 (n - k))  clipped to the layer's plane extent [-(n - k), H + (n - k))
+    // of a band [y0, y1) instead of [y0 - (n - k), y1 + (n - k)): every region edge that is not a plane edge is a block edge (blocks sit on rows
+    // = 0 mod 4 of the plane), and layer k + 1 finds the rows it reads (one more each side) inside.  Costs up to 3 + 3 (n - k) more rows per side.
+    w2xc_opts o = o_in;
+    int HL = 1;
+    if (uses_wino4(m, o)) {
+        const int hs = 4 * n;
+        if (plane_h > 0 && vy0 <= std::max(0, ra - hs) && vy0 + vh >= std::min(plane_h, rb + hs)) HL = 4;
+        else if (o.kernel == W2XC_KERNEL_AUTO) o.kernel = W2XC_KERNEL_WINOGRAD;   // a view with n halo rows only: the banding-invariant F(2x2) kernels
+        // (an explicit W2XC_KERNEL_WINOGRAD4 on a narrow view runs as asked: results then depend on the banding at rounding level)
+    }
+    auto region = [&](int k, int y0, int y1, int &T, int &B) {   // plane rows [T, B) layer k computes for the band [y0, y1)
+        if (HL == 1 || k == n) { T = y0 - (n - k); B = y1 + (n - k); return; }
+        T = std::max(-(n - k), (y0 & ~3) - 4 * (n - k));
+        B = std::min(plane_h + (n - k), ((y1 + 3) & ~3) + 4 * (n - k));
+    };
     if (m->layers[0].nin != n_in)   // convertWithModelsBasic pushes exactly one plane (convertRoutine.cpp:63-64)
         return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", n_in, m->layers[0].nin);
     const bool all_out = out_cs != 0;   // multi-plane output
@@ -588,7 +634,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         for (int k = 1; k <= n; k++) {
             if (k == n && last_direct) break;   // written straight to d_out
             if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
-            const size_t hk = (size_t)rows + 2 * (n - k), wk = (size_t)w + 2 * (n - k);
+            const size_t hk = (size_t)rows + ((HL == 1 || k == n) ? 2 * (n - k) : 6 + 8 * (n - k)), wk = (size_t)w + 2 * (n - k);
             const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
             const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * px_bytes);
@@ -623,6 +669,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             band = (total + nb - 1) / nb;   // equalise (never larger than the band that was just checked)
         }
     }
+    if (HL > 1 && band < total) band = std::max(4, band & ~3);   // (band edges on block rows: no rounding-out rows)
     band = std::min(band, total);
     {
         size_t need[2];
@@ -643,6 +690,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         W2xcConvDesc first_d;
         memset(&first_d, 0, sizeof first_d);
         int src_h = vh, src_w = w;
+        int Tprev = vy0;   // first plane row held by the buffer layer k reads (the source view for k = 1)
         for (int k = 1; k <= n; k++) {
             if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
             const HostLayer &hl = m->layers[k - 1];
@@ -650,12 +698,15 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             memset(&d, 0, sizeof d);
             d.in = src; d.in_rs = src_rs; d.in_ps = src_ps; d.in_cs = src_cs;
             d.in_h = src_h; d.in_w = src_w;
-            d.out_h = (y1 - y0) + 2 * (n - k);
+            int Tk, Bk;
+            region(k, y0, y1, Tk, Bk);
+            d.out_h = Bk - Tk;
             d.out_w = w + 2 * (n - k);
-            d.off_y = k == 1 ? (y0 - n - vy0) : 0;
+            d.off_y = Tk - 1 - Tprev;   // (k = 1: y0 - n - vy0; k > 1: 0 on the one-row-per-layer geometry)
+            Tprev = Tk;
             d.off_x = k == 1 ? -n : 0;
             // this launch's first output row in the coordinates of the whole plane, modulo the Winograd block height (2; conv3x3_wino4: 4)
-            d.wino_py = (y0 - (n - k)) & ((hl.nin >= 32 && hl.nout >= 32 && mid_variant_for(mid_variant(o), hl.nin, hl.nout) == MID_WINO4) ? 3 : 1);
+            d.wino_py = Tk & ((w2xc_pick_kernel(hl.nin, hl.nout) == W2XC_K_MFMA && layer_mid_variant(m, k - 1, o) == MID_WINO4) ? 3 : 1);
             d.in_shift = k == 1 ? up : 0;
             const W2xcKernelKind kind = layer_kind(m, k - 1, o);
             if (kind == W2XC_K_FUSED_AWAY) {   // layer 1 inside layer 2's kernel: keep its input description for that launch
@@ -670,7 +721,12 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             int split_grp = 0;
             if (T == 0) {   // fp32: only the fused last layer uses the term fields
                 d.out_terms = out_terms_of(m, k - 1, o);
-                if (kind == W2XC_K_LAST_GATHER) { d.halves = src_halves; d.in_ts = src_ts; d.in_gs = src_gs; }
+                if (kind == W2XC_K_LAST_GATHER) {
+                    d.halves = src_halves; d.in_ts = src_ts; d.in_gs = src_gs;
+                    d.in += (long long)d.off_y * d.in_rs;   // (no offsets in that kernel; off_y > 0 on the four-rows-per-layer geometry only)
+                    d.in_h -= d.off_y;
+                    d.off_y = 0;
+                }
             }
             if (T > 0) {
                 d.terms = (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) ? T : 0;
@@ -707,8 +763,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             // band's download behind.  So layer n-1 and the gather run TOGETHER in row chunks (quarters of the band, whole 16-row
             // tiles): chunk j's rows leave for the host under layer n-1 of chunk j+1.  The producer chunks tile the G rows without
             // overlap (chunk j computes G rows up to r1 + 2, the next one continues there): no recompute.
-            if (hk && k == n - 1 && n >= 3 && (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_MFMA) && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
-                hk->output_ready && (y1 - y0) >= 128) {
+            if (hk && HL == 1 && k == n - 1 && n >= 3 && (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_MFMA) && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
+                hk->output_ready && (y1 - y0) >= 128) {   // (HL = 4: the producer's rows do not start one above the band's: the unchunked path)
                 if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
                 const int R = y1 - y0;
                 const int cr = std::max(64, ((R / 4) + 15) & ~15);
@@ -1036,7 +1092,7 @@ try {
     rc = get_ctx(m, dev, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o);
+    return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o, 0, 1, 0, 0, nullptr, h);
 } W2XC_CATCH_ALL
 
 int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_stride_bytes, int view_h, int view_y0, int w,
@@ -1063,8 +1119,10 @@ try {
     std::lock_guard<std::mutex> lk(c->mu);
     // a view that starts/ends inside the plane has artificial edges, but every row within n of
     // them lies outside [row_begin, row_end), so clamping there never reaches a kept output row
+    // (conv3x3_wino4, the F(4x4) kernel: a view with 4 n halo rows -- w2xc_shard_view's -- gets its banding-invariant geometry; on a narrower one
+    //  W2XC_KERNEL_AUTO runs the F(2x2) kernels: run_rows)
     return run_rows(m, c, d_view, view_stride_bytes / 4, view_h, view_y0, w, row_begin, row_end, d_out,
-                    out_stride_bytes / 4, (hipStream_t)hip_stream, o);
+                    out_stride_bytes / 4, (hipStream_t)hip_stream, o, 0, 1, 0, 0, nullptr, plane_h);
 } W2XC_CATCH_ALL
 
 }  // extern "C"
@@ -1246,8 +1304,9 @@ int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot,
 //                          convertRoutine.cpp:143-161), freeing the slot
 // so H2D(band k+1) || layers(band k) || D2H + stitch(band k-1 / earlier chunks).  Planes that are already pinned
 // are DMA'd in place without staging.
+// hs = halo rows of the source view per side (src_halo_rows: n, or 4 n for the banding-invariant geometry of conv3x3_wino4)
 int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stride, int w, int h, int up, int ra, int rb,
-                        float *out_, size_t out_stride, const w2xc_opts &o, int copy_threads, int in_row0, int out_row0)
+                        float *out_, size_t out_stride, const w2xc_opts &o, int copy_threads, int in_row0, int out_row0, int hs)
 {
     // `in_` points at source row in_row0, `out_` at output row out_row0: rebase both to row 0 (only rows that exist are touched)
     const float *in = (const float *)((const char *)in_ - (ptrdiff_t)in_row0 * (ptrdiff_t)in_stride);
@@ -1266,8 +1325,8 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
 
     const int n = (int)m->layers.size();
     const int W = w << up, H = h << up;
-    // source rows that cover output rows [ra - n, rb + n) (clipped), in source coordinates
-    const int sy0 = std::max(0, ra - n) >> up, sy1 = (std::min(H, rb + n) + up) >> up;
+    // source rows that cover output rows [ra - hs, rb + hs) (clipped), in source coordinates
+    const int sy0 = std::max(0, ra - hs) >> up, sy1 = (std::min(H, rb + hs) + up) >> up;
     const int svh = sy1 - sy0;
     const size_t in_row = (size_t)w * 4, out_row = (size_t)W * 4;
     const bool in_pinned = host_range_pinned((const char *)in + (size_t)sy0 * in_stride, (size_t)(svh - 1) * in_stride + in_row);
@@ -1318,7 +1377,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     const char *out_lo = (const char *)out + (size_t)ra * out_stride, *out_hi = (const char *)out + (size_t)(rb - 1) * out_stride + out_row;
     const bool overlap = in_lo < out_hi && out_lo < in_hi;
     // view rows (source coordinates, relative to sy0) a band of output rows [y0, y1) reads
-    auto band_src_end = [&](int y1) { return overlap ? svh : ((std::min(H, y1 + n) + up) >> up) - sy0; };
+    auto band_src_end = [&](int y1) { return overlap ? svh : ((std::min(H, y1 + hs) + up) >> up) - sy0; };
 
     // ---- output side ----
     struct Chunk { int r0, r1, slot; };
@@ -1438,7 +1497,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     static const bool trace = getenv("W2XC_HOST_TRACE") != nullptr;   // (debug aid) phase timestamps of one unit on stderr
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-    rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk);
+    rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk, H);
     const double t_enq = ms_since(t0);
     double t_comp = 0;
     if (trace) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
@@ -1477,7 +1536,16 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         if (in_row0 < 0 || in_row0 > need0 || in_row0 + in_rows < need1 || in_row0 + in_rows > h)
             return fail(W2XC_ERR_ARG, "source rows [%d,%d) do not cover the rows [%d,%d) this row range reads", in_row0, in_row0 + in_rows, need0, need1);
     }
-    const w2xc_opts o = resolve_opts(opts);
+    w2xc_opts o = resolve_opts(opts);
+    // halo rows of the units' source views: n, or 4 n when conv3x3_wino4 runs (its banding-invariant geometry, run_rows) -- if the rows handed
+    // over hold that much around [row_begin, row_end); otherwise W2XC_KERNEL_AUTO means the F(2x2) kernels for this call
+    int hs = (int)m->layers.size();
+    if (uses_wino4(m, o)) {
+        const int h4 = 4 * hs;
+        const int need0 = std::max(0, row_begin - h4) >> up, need1 = (std::min(H, row_end + h4) + up) >> up;
+        if (in_row0 <= need0 && in_row0 + in_rows >= need1) hs = h4;
+        else if (o.kernel == W2XC_KERNEL_AUTO) o.kernel = W2XC_KERNEL_WINOGRAD;
+    }
     const int ndev_all = w2xc_device_count();
     if (ndev_all <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
     std::vector<int> devs;
@@ -1503,8 +1571,7 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
     // (convertRoutine.cpp:35,96); here the source rows are snapshotted once before the units fan out.
     std::vector<float> snapshot;
     if (nd > 1) {
-        const int n = (int)m->layers.size();
-        const int s0 = std::max(0, row_begin - n) >> up, s1 = (std::min(H, row_end + n) + up) >> up;
+        const int s0 = std::max(0, row_begin - hs) >> up, s1 = (std::min(H, row_end + hs) + up) >> up;
         const char *in_lo = (const char *)in + (ptrdiff_t)(s0 - in_row0) * (ptrdiff_t)in_stride_bytes;
         const char *in_hi = (const char *)in + (ptrdiff_t)(s1 - 1 - in_row0) * (ptrdiff_t)in_stride_bytes + (size_t)w * 4;
         const char *out_lo = (const char *)out, *out_hi = (const char *)out + (size_t)(R - 1) * out_stride_bytes + (size_t)W * 4;
@@ -1529,7 +1596,7 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         // contiguous share [ra, rb) of the OUTPUT rows for unit t: independent, no exchange
         const int ra = row_begin + (int)((long long)R * t / nd), rb = row_begin + (int)((long long)R * (t + 1) / nd);
         try {   // no exception may leave a unit's thread (std::terminate) or cross the C ABI
-            rcs[t] = host_rows_on_device(m, devs[t], in, in_stride_bytes, w, h, up, ra, rb, out, out_stride_bytes, o, copy_threads, in_row0, row_begin);
+            rcs[t] = host_rows_on_device(m, devs[t], in, in_stride_bytes, w, h, up, ra, rb, out, out_stride_bytes, o, copy_threads, in_row0, row_begin, hs);
             if (rcs[t]) errs[t] = g_last_error;
         } catch (const std::bad_alloc &) {
             rcs[t] = W2XC_ERR_NOMEM;
@@ -1599,7 +1666,7 @@ try {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     return run_rows(m, c, d_in, in_stride_bytes / 4, h, 0, w, 0, h, d_out, out_stride_bytes / 4, (hipStream_t)hip_stream, o, 0,
-                    n_in_planes, (long long)(in_plane_stride_bytes / 4), (long long)(out_plane_stride_bytes / 4));
+                    n_in_planes, (long long)(in_plane_stride_bytes / 4), (long long)(out_plane_stride_bytes / 4), nullptr, h);
 } W2XC_CATCH_ALL
 
 int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_stride_bytes, int w, int h, float *d_out,
@@ -1619,7 +1686,7 @@ try {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     return run_rows(m, c, d_in, in_stride_bytes / 4, 2 * h, 0, 2 * w, 0, 2 * h, d_out, out_stride_bytes / 4,
-                    (hipStream_t)hip_stream, o, 1);
+                    (hipStream_t)hip_stream, o, 1, 1, 0, 0, nullptr, 2 * h);
 } W2XC_CATCH_ALL
 
 }  // extern "C"
@@ -1892,7 +1959,7 @@ int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs
     base = yn + (size_t)cw * ch;
     HIP_TRY(w2xc_launch_u8_to_yuv(d_in, in_stride, w, h, y, u, v, st));                                   // :75-76
     if (mn) {                                                                                             // :91-98
-        int rc = run_rows(mn, cn, y, cw, ch, 0, cw, 0, ch, yn, cw, st, o, 0);
+        int rc = run_rows(mn, cn, y, cw, ch, 0, cw, 0, ch, yn, cw, st, o, 0, 1, 0, 0, nullptr, ch);
         if (rc) return rc;
         y = yn;
     }
@@ -1901,7 +1968,7 @@ int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs
         float *y2 = base, *u2 = y2 + (size_t)nw * nh, *v2 = u2 + (size_t)nw * nh;
         base = v2 + (size_t)nw * nh;
         // Y: INTER_NEAREST 2x folded into layer 1 (:136-140) + convertWithModels (:148)
-        int rc = run_rows(msc, cs, y, cw, nh, 0, nw, 0, nh, y2, nw, st, o, 1);
+        int rc = run_rows(msc, cs, y, cw, nh, 0, nw, 0, nh, y2, nw, st, o, 1, 1, 0, 0, nullptr, nh);
         if (rc) return rc;
         HIP_TRY(w2xc_launch_resize2x_cubic(u, cw, ch, u2, st));                                            // :144-146
         HIP_TRY(w2xc_launch_resize2x_cubic(v, cw, ch, v2, st));
@@ -2112,7 +2179,7 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     const w2xc_opts o = resolve_opts(opts);
     const W2xcKernelKind k = layer_kind(m, layer, o);
     if (k == W2XC_K_MFMA) {
-        const int midv = mid_variant_for(mid_variant(o), m->layers[layer].nin, m->layers[layer].nout);
+        const int midv = layer_mid_variant(m, layer, o);
         if (midv != MID_MFMA) return midv == MID_WINO4 ? "conv3x3_wino4" : midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
     }
     return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
