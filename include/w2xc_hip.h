@@ -57,15 +57,18 @@ typedef struct w2xc_model w2xc_model;
                                  * 2^-3 -- meant for image planes in [0, 1].                   */
 
 #define W2XC_KERNEL_AUTO    0   /* the fast kernel of each layer shape; for the fp32 layers with 32 / 64 / 128 planes in and out that
-                                 * is the process default: Winograd (conv3x3_wino16) unless the environment says W2XC_WINOGRAD=0
-                                 * (then W2XC_KERNEL_MFMA) or W2XC_WINO_KERNEL=32 (then W2XC_KERNEL_WINOGRAD32)            */
+                                 * is the process default: Winograd F(4x4,3x3) (conv3x3_wino4; F(2x2,3x3) where it does not apply: 32 output
+                                 * planes, or a row-band view without the wide halo below) unless the environment says W2XC_WINOGRAD=0
+                                 * (then W2XC_KERNEL_MFMA), W2XC_WINO_KERNEL=16 (W2XC_KERNEL_WINOGRAD) or =32 (W2XC_KERNEL_WINOGRAD32) */
 #define W2XC_KERNEL_DIRECT  1   /* every layer: reference-ordered direct conv on VALU (bit-exact vs the oracle)             */
 #define W2XC_KERNEL_MFMA    2   /* mid layers: direct implicit GEMM, a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32
                                  * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
 #define W2XC_KERNEL_WINOGRAD 3  /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (conv3x3_wino16), fp32 throughout */
 #define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: the round-2 Winograd kernel on v_mfma_f32_32x32x2_f32 (conv3x3_wino)        */
 #define W2XC_KERNEL_WINOGRAD4 5 /* mid layers with >= 64 output planes: Winograd F(4x4,3x3) (conv3x3_wino4), fp32 throughout: 2.25 multiplies per
-                                 * output instead of 4, rounding error ~8x F(2x2)'s (still 3-5x inside rtol 1e-4); env W2XC_WINO_KERNEL=4  */
+                                 * output instead of 4, interpolation points 0, +-3/4, +-3/2 (rounding error ~1.3x F(2x2)'s, every rtol 1e-4 gate
+                                 * holds).  What W2XC_KERNEL_AUTO picks; asked for explicitly it also runs on row-band views with the
+                                 * minimum halo, where its results depend on the banding at rounding level                            */
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */
@@ -161,7 +164,11 @@ int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride
  * convertRoutine.cpp:114-165, made parallel): computes output rows [row_begin, row_end) of the
  * plane_h x w conversion.  `d_view` holds plane rows [view_y0, view_y0 + view_h) and must cover
  * [row_begin - n_layers, row_end + n_layers) clipped to the plane; `d_out` points at output row
- * row_begin.  Device pointers, asynchronous on `hip_stream`, no exchange between bands. */
+ * row_begin.  Device pointers, asynchronous on `hip_stream`, no exchange between bands.
+ * Bands stitch BIT-identically with the whole-plane call when the view holds the WIDE halo,
+ * [row_begin - 4 n_layers, row_end + 4 n_layers) clipped: the default F(4x4) mid-layer kernel works on 4x4 blocks
+ * and needs every band region to end on a block row, four rows of halo per layer.  On a view with only the minimum
+ * halo W2XC_KERNEL_AUTO runs the F(2x2) kernels for the call -- same tolerance, another rounding (1e-6 of the range). */
 int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_stride_bytes, int view_h,
                              int view_y0, int w, int plane_h, int row_begin, int row_end, float *d_out,
                              size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);
@@ -191,7 +198,8 @@ int w2xc_convert_plane_nn2x_device(w2xc_model *m, const float *d_in, size_t in_s
  * processes): output rows [row_begin, row_end) of the conversion of a w x h source plane (nn2x = 1: of its nearest-
  * neighbour 2x, main.cpp:132-140, so the output plane is 2w x 2h and row numbers are in OUTPUT coordinates).
  * `in_view` points at source row view_y0 and holds view_h rows, which must cover every source row the range reads
- * (rows [row_begin - n_layers, row_end + n_layers) of the plane, halved for nn2x, clipped); `out` points at output row
+ * (rows [row_begin - n_layers, row_end + n_layers) of the plane, halved for nn2x, clipped -- 4 n_layers instead of n_layers
+ * for units that stitch bit-identically with the whole-plane call, see w2xc_convert_rows_device); `out` points at output row
  * row_begin.  Same pinned-staged, overlapped pipeline and device_mask semantics as w2xc_convert_plane; units never
  * exchange data, so N processes each calling this with their own row range ARE the multi-GPU farm (host-side gather only). */
 int w2xc_convert_plane_rows(w2xc_model *m, const float *in_view, size_t in_stride_bytes, int view_y0, int view_h, int w, int h,
