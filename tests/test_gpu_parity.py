@@ -226,6 +226,31 @@ def test_row_band_entry_point(gpu, scale_layers, parts, precision):
     assert e.value.code == gpu.ERR_ARG
 
 
+def test_row_bands_on_minimum_halo_views_run_the_f2x2_kernels(gpu, scale_layers):
+    """The default F(4x4) mid-layer kernel needs 4 n halo rows in a band's view for its banding-invariant geometry.  A caller
+    that passes the MINIMUM view ([ra - n, rb + n), what the entry point has always accepted) gets the F(2x2) kernels for that call
+    under W2XC_KERNEL_AUTO: the bands stitch bit-identically with the whole-plane run of THOSE kernels (w2xc_opts.kernel =
+    W2XC_KERNEL_WINOGRAD) and sit within the usual tolerance of the oracle and of the default whole-plane run."""
+    torch = pytest.importorskip("torch")
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    h, w, parts = 150, 90, 3
+    x = rand_plane(h, w, 13)
+    out = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    o = gpu.make_opts(device=0)
+    for p in range(parts):
+        ra, rb = gpu.shard_rows(h, parts, p)
+        y0, y1 = gpu.shard_view(h, ra, rb, ms.n_layers)
+        view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
+        ms.convert_rows_device(view.data_ptr(), w * 4, y1 - y0, y0, w, h, ra, rb, out[ra:].data_ptr(), w * 4, stream=st.cuda_stream, opts=o)
+    st.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD)))
+    assert_close(got, orc.Oracle(scale_layers).convert(x, njob=8), "minimum-halo row bands")
+    whole = ms.convert(x)
+    assert np.abs(got - whole).max() <= 1e-5 * np.abs(whole).max()
+
+
 @pytest.mark.parametrize("h,w", [(37, 53), (1, 1), (128, 160)])
 def test_nn2x_fused_into_layer1(gpu, scale_layers, h, w):
     """N1: cv::resize(INTER_NEAREST, 2x) + convertWithModels (main.cpp:132-148) as one call equals
