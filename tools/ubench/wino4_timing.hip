@@ -59,5 +59,19 @@ int main(int argc, char **argv)
         }
         printf("   epilogue %5.0f   item %.0f  (%.0f per stage)\n", epi / items, tot, tot / nst);
     }
+    // slot stamps inside a stage: the transforming stage of waves 0 / 4 and a plain stage of the same waves (every third MFMA, then the stage's end)
+    static unsigned long long sl[2][2][64][40];
+    hipMemcpyFromSymbol(sl, HIP_SYMBOL(w4_slots), sizeof sl);
+    for (int g = 0; g < 2; g++)
+        for (int tr = 0; tr < 2; tr++) {
+            printf("wave %d %s stage, cycles from the first MFMA to MFMA #: ", 4 * g, tr ? "TRANSFORMING" : "plain");
+            for (int x = 3; x <= 36; x += 3) {
+                double sum = 0; int cnt = 0;
+                for (int k = 0; k < 64; k++)
+                    if (sl[g][tr][k][0] && sl[g][tr][k][x] > sl[g][tr][k][0]) { sum += (double)(sl[g][tr][k][x] - sl[g][tr][k][0]); cnt++; }
+                printf("%d:%.0f ", x, cnt ? sum / cnt : 0.0);
+            }
+            printf("\n");
+        }
     return 0;
 }
