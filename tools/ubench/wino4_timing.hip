@@ -59,6 +59,7 @@ int main(int argc, char **argv)
         }
         printf("   epilogue %5.0f   item %.0f  (%.0f per stage)\n", epi / items, tot, tot / nst);
     }
+#ifdef W4_SLOT_STAMPS   // (needs the per-slot W4_SLOT stamps compiled into the kernel: the patch is described in profiles/r3_sweeps.log block 21)
     // slot stamps inside a stage: the transforming stage of waves 0 / 4 and a plain stage of the same waves (every third MFMA, then the stage's end)
     static unsigned long long sl[2][2][64][40];
     hipMemcpyFromSymbol(sl, HIP_SYMBOL(w4_slots), sizeof sl);
@@ -73,5 +74,6 @@ int main(int argc, char **argv)
             }
             printf("\n");
         }
+#endif
     return 0;
 }
