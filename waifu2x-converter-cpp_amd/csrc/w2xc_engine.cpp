@@ -1323,7 +1323,6 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     HostPipe &p = c->pipe;
     if ((rc = pipe_init(p))) return rc;
 
-    const int n = (int)m->layers.size();
     const int W = w << up, H = h << up;
     // source rows that cover output rows [ra - hs, rb + hs) (clipped), in source coordinates
     const int sy0 = std::max(0, ra - hs) >> up, sy1 = (std::min(H, rb + hs) + up) >> up;
