@@ -458,10 +458,6 @@ bool uses_wino4(const w2xc_model *m, const w2xc_opts &o)
         if (w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout) == W2XC_K_MFMA && layer_mid_variant(m, l, o) == MID_WINO4) return true;
     return false;
 }
-// halo rows (per side, clipped to the plane) the SOURCE view of rows [ra, rb) should hold: n = one per layer; 4 n for the banding-invariant
-// geometry of conv3x3_wino4 (per-layer regions rounded out to multiples of 4 rows and grown by 4 rows per layer)
-int src_halo_rows(const w2xc_model *m, const w2xc_opts &o) { return (int)m->layers.size() * (uses_wino4(m, o) ? 4 : 1); }
-
 // fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
 // the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
 // w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
@@ -1119,7 +1115,7 @@ try {
     std::lock_guard<std::mutex> lk(c->mu);
     // a view that starts/ends inside the plane has artificial edges, but every row within n of
     // them lies outside [row_begin, row_end), so clamping there never reaches a kept output row
-    // (conv3x3_wino4, the F(4x4) kernel: a view with 4 n halo rows -- w2xc_shard_view's -- gets its banding-invariant geometry; on a narrower one
+    // (conv3x3_wino4, the F(4x4) kernel: a view with 4 n halo rows gets its banding-invariant geometry; on a narrower one
     //  W2XC_KERNEL_AUTO runs the F(2x2) kernels: run_rows)
     return run_rows(m, c, d_view, view_stride_bytes / 4, view_h, view_y0, w, row_begin, row_end, d_out,
                     out_stride_bytes / 4, (hipStream_t)hip_stream, o, 0, 1, 0, 0, nullptr, plane_h);
@@ -1304,7 +1300,7 @@ int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot,
 //                          convertRoutine.cpp:143-161), freeing the slot
 // so H2D(band k+1) || layers(band k) || D2H + stitch(band k-1 / earlier chunks).  Planes that are already pinned
 // are DMA'd in place without staging.
-// hs = halo rows of the source view per side (src_halo_rows: n, or 4 n for the banding-invariant geometry of conv3x3_wino4)
+// hs = halo rows of the source view per side (convert_plane_host decides: n, or 4 n for the banding-invariant geometry of conv3x3_wino4)
 int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stride, int w, int h, int up, int ra, int rb,
                         float *out_, size_t out_stride, const w2xc_opts &o, int copy_threads, int in_row0, int out_row0, int hs)
 {
