@@ -1,0 +1,134 @@
+"""CPU checks of the Winograd F(4x4,3x3) algebra behind conv3x3_wino4 (no GPU: the library's HOST weight transform + numpy).
+
+The kernel computes Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A on the interpolation points 0, +-3/4, +-3/2, inf
+(waifu2x-converter-cpp_amd/csrc/w2xc_wino4.hip: bt6 / at6 / w2xc_wino4_pack).  Here: the transformed weights are taken from the
+library's own w2xc_wino4_pack (a host function; an internal symbol, not part of the C ABI), un-permuted by the documented fragment layout,
+and combined with B^T and A^T restated from bt6 / at6 -- the result has to be the 3x3 correlation of modelHandler.cpp:127-145
+(filter2D per input plane, summed) on every 6x6 patch, to fp32 rounding of U.  A mismatch between the three matrices, or a weight image
+whose layout is not the one the kernel's fragment reads assume, fails here without a GPU.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+# y = B^T x as bt6 computes it (w2xc_wino4.hip: bt6)
+BT = np.array([
+    [1.265625, 0.0, -2.8125, 0.0, 1.0, 0.0],
+    [0.0, -1.6875, -2.25, 0.75, 1.0, 0.0],
+    [0.0, 1.6875, -2.25, -0.75, 1.0, 0.0],
+    [0.0, -0.84375, -0.5625, 1.5, 1.0, 0.0],
+    [0.0, 0.84375, -0.5625, -1.5, 1.0, 0.0],
+    [0.0, 1.265625, 0.0, -2.8125, 0.0, 1.0],
+])
+# y = A^T m as at6 computes it (w2xc_wino4.hip: at6)
+AT = np.array([
+    [1.0, 1.0, 1.0, 1.0, 1.0, 0.0],
+    [0.0, 0.75, -0.75, 1.5, -1.5, 0.0],
+    [0.0, 0.5625, 0.5625, 2.25, 2.25, 0.0],
+    [0.0, 0.421875, -0.421875, 3.375, -3.375, 1.0],
+])
+
+
+def _pack(w2xc, cin, cout, w):
+    lib = ctypes.CDLL(w2xc.LIB_PATH)
+    fn = getattr(lib, "_Z15w2xc_wino4_packiiPKfPf")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    dst = np.zeros(36 * cin * cout, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    fn(cin, cout, w.ctypes.data, dst.ctypes.data)
+    return dst
+
+
+def _unpack(cin, cout, img):
+    """U[xi][plane][channel] from [ob][s][xi / 4][pt][lane = 16 k + o][xi % 4] (w2xc_wino4_pack's comment)."""
+    nst, nob = cin // 4, cout // 64
+    a = img.reshape(nob, nst, 9, 4, 4, 16, 4)          # ob, s, xi >> 2, pt, k, o, xi & 3
+    a = a.transpose(2, 6, 0, 3, 5, 1, 4)                # xi >> 2, xi & 3, ob, pt, o, s, k
+    return a.reshape(36, cout, cin)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (128, 128)])
+def test_wino4_weight_image_and_matrices_reproduce_the_3x3_correlation(w2xc, cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    U = _unpack(cin, cout, _pack(w2xc, cin, cout, w)).astype(np.float64)
+    assert np.isfinite(U).all() and np.abs(U).max() > 0
+    d = rng.standard_normal((cin, 6, 6)).astype(np.float32).astype(np.float64)
+    V = np.einsum("ia,cab,jb->cij", BT, d, BT).reshape(cin, 36)           # B^T d B per channel
+    M = np.einsum("xpc,cx->px", U, V).reshape(cout, 6, 6)                 # the 36 xi GEMMs
+    Y = np.einsum("ia,pab,jb->pij", AT, M, AT)                            # A^T M A: 4x4 outputs per plane
+    ref = np.zeros((cout, 4, 4))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum("pc,cyx->pyx", w[:, :, ky, kx].astype(np.float64), d[:, ky:ky + 4, kx:kx + 4])
+    scale = np.abs(ref).max()
+    # U is rounded to fp32 once (2^-24 relative per term, cin * 36 terms, transform gains of a few units): 1e-5 of the range is ~30x that
+    assert np.abs(Y - ref).max() <= 1e-5 * scale, (np.abs(Y - ref).max(), scale)
+
+
+def test_wino4_matrices_are_the_cook_toom_matrices_of_their_points(w2xc):
+    """B^T, A^T and the G implied by the weight image belong to the points 0, +-3/4, +-3/2, inf: F(4,3) in one dimension, exactly (float64)."""
+    rng = np.random.default_rng(7)
+    g = rng.standard_normal(3)
+    x = rng.standard_normal(6)
+    pts = [0.0, 0.75, -0.75, 1.5, -1.5]
+    # G g = g evaluated at the points, scaled by 1 / prod_{k != i} (p_i - p_k); last row = leading coefficient
+    G = np.zeros((6, 3))
+    for i, p in enumerate(pts):
+        den = np.prod([p - q for k, q in enumerate(pts) if k != i])
+        G[i] = np.array([1.0, p, p * p]) / den
+    G[5] = [0.0, 0.0, 1.0]
+    y = AT @ ((G @ g) * (BT @ x))
+    ref = np.array([np.dot(g, x[k:k + 3]) for k in range(4)])
+    assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # and the library's image uses that G (up to the rounding of U): one plane block, channel 0 carries g (x) g
+    w = np.zeros((64, 32, 3, 3), np.float32)
+    g32 = g.astype(np.float32)
+    w[0, 0] = np.outer(g32, g32)
+    U = _unpack(32, 64, _pack(w2xc, 32, 64, w))[:, 0, 0].reshape(6, 6).astype(np.float64)
+    expect = G @ w[0, 0].astype(np.float64) @ G.T
+    assert np.abs(U - expect).max() <= 2.0 ** -23 * np.abs(expect).max()
+
+
+# ---- F(2x2,3x3): conv3x3_wino16 (w2xc_wino16.hip; W2XC_KERNEL_WINOGRAD, and the row-band fallback of W2XC_KERNEL_AUTO) ----
+BT2 = np.array([[1.0, 0.0, -1.0, 0.0], [0.0, 1.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.0], [0.0, 1.0, 0.0, -1.0]])
+AT2 = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
+
+
+def _pack16(w2xc, cin, cout, w):
+    lib = ctypes.CDLL(w2xc.LIB_PATH)
+    fn = getattr(lib, "_Z16w2xc_wino16_packiiPKfPf")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    dst = np.zeros(16 * cin * cout, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    fn(cin, cout, w.ctypes.data, dst.ctypes.data)
+    return dst
+
+
+def _unpack16(cin, cout, img):
+    """U[xi][plane][channel] from [ob][slice][st][pt][xi / 4][lane = 16 kq + o][xi % 4], channel = 8 slice + 2 kq + st (w2xc_wino16_pack's comment)."""
+    nsl, nob = cin // 8, cout // 32
+    a = img.reshape(nob, nsl, 2, 2, 4, 4, 16, 4)        # ob, sl, st, pt, xi >> 2, kq, o, xi & 3
+    a = a.transpose(4, 7, 0, 3, 6, 1, 5, 2)              # xi >> 2, xi & 3, ob, pt, o, sl, kq, st
+    return a.reshape(16, cout, cin)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (128, 128)])
+def test_wino16_weight_image_and_matrices_reproduce_the_3x3_correlation(w2xc, cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout + 1)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    U = _unpack16(cin, cout, _pack16(w2xc, cin, cout, w)).astype(np.float64)
+    d = rng.standard_normal((cin, 4, 4)).astype(np.float32).astype(np.float64)
+    V = np.einsum("ia,cab,jb->cij", BT2, d, BT2).reshape(cin, 16)
+    M = np.einsum("xpc,cx->px", U, V).reshape(cout, 4, 4)
+    Y = np.einsum("ia,pab,jb->pij", AT2, M, AT2)
+    ref = np.zeros((cout, 2, 2))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum("pc,cyx->pyx", w[:, :, ky, kx].astype(np.float64), d[:, ky:ky + 2, kx:kx + 2])
+    scale = np.abs(ref).max()
+    assert np.abs(Y - ref).max() <= 2e-6 * scale, (np.abs(Y - ref).max(), scale)
