@@ -132,3 +132,58 @@ def test_wino16_weight_image_and_matrices_reproduce_the_3x3_correlation(w2xc, ci
             ref += np.einsum("pc,cyx->pyx", w[:, :, ky, kx].astype(np.float64), d[:, ky:ky + 2, kx:kx + 2])
     scale = np.abs(ref).max()
     assert np.abs(Y - ref).max() <= 2e-6 * scale, (np.abs(Y - ref).max(), scale)
+
+
+# ---- the fp32 error of F(4x4,3x3) as the kernel orders it, emulated in numpy float32 ----
+def _bt6_f32(x0, x1, x2, x3, x4, x5):
+    """bt6 of w2xc_wino4.hip on float32 arrays (numpy rounds the product and the sum separately where the kernel's fma rounds once: an upper bound)."""
+    f = np.float32
+    y0 = f(-2.8125) * x2 + (f(1.265625) * x0 + x4)
+    p, q = f(-2.25) * x2 + x4, f(-1.6875) * x1 + f(0.75) * x3
+    u, v = f(-0.5625) * x2 + x4, f(-0.84375) * x1 + f(1.5) * x3
+    y5 = f(-2.8125) * x3 + (f(1.265625) * x1 + x5)
+    return y0, p + q, p - q, u + v, u - v, y5
+
+
+def _at6_f32(m0, m1, m2, m3, m4, m5):
+    f = np.float32
+    s1, d1, s2, d2 = m1 + m2, m1 - m2, m3 + m4, m3 - m4
+    return m0 + s1 + s2, f(1.5) * d2 + f(0.75) * d1, f(2.25) * s2 + f(0.5625) * s1, f(3.375) * d2 + (f(0.421875) * d1 + m5)
+
+
+@pytest.mark.parametrize("data", ["image", "normal"])
+def test_wino4_fp32_error_meets_the_elementwise_gate(w2xc, data):
+    """128 -> 128 planes, weights drawn like the upstream initialisation, on 36 output tiles: F(4x4,3x3) in float32 -- the library's weight image, the
+    column-then-row input transform, an fp32 accumulation over the channels in stage order, the row-pair output transform, bias, LeakyReLU -- against the
+    float64 correlation of modelHandler.cpp:127-154, at the gate the GPU parity tests use (|got - want| <= 1e-5 + 1e-4 |want|).  `image`: inputs in [0, 1)
+    like a luma plane / an activation; `normal`: zero-mean unit-variance inputs, the cancellation-heavy case the interpolation points were chosen on
+    (tools/winograd_points.py: the Lavin-Gray points 0, +-1, +-2 fail it by 3x)."""
+    cin = cout = 128
+    rng = np.random.default_rng(11 if data == "image" else 12)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (1.01 * 9 * cin))).astype(np.float32)
+    bias = (rng.standard_normal(cout) * 0.01).astype(np.float32)
+    th = tw = 6                                                        # 6 x 6 tiles of 4 x 4 outputs: a 26 x 26 input
+    x = (rng.random((cin, 4 * th + 2, 4 * tw + 2)) if data == "image" else rng.standard_normal((cin, 4 * th + 2, 4 * tw + 2))).astype(np.float32)
+    U = _unpack(cin, cout, _pack(w2xc, cin, cout, w))                  # [36][plane][channel], float32
+    d = np.stack([x[:, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6] for ty in range(th) for tx in range(tw)])            # [tile][channel][6][6]
+    t = np.stack(_bt6_f32(*[d[:, :, i, :] for i in range(6)]), axis=2)                                            # columns first: over the row index
+    V = np.stack(_bt6_f32(*[t[:, :, :, j] for j in range(6)]), axis=3).reshape(len(d), cin, 36)                   # then along each row
+    acc = np.zeros((len(d), cout, 36), np.float32)
+    for c in range(cin):                                               # channel order = stage order (4 per MFMA, k ascending)
+        acc = acc + U[:, :, c].T[None, :, :] * V[:, c, None, :]
+    M = acc.reshape(len(d), cout, 6, 6)
+    tm = np.stack(_at6_f32(*[M[:, :, i, :] for i in range(6)]), axis=2)                                           # A^T M: 4 x 6
+    Y = np.stack(_at6_f32(*[tm[:, :, :, j] for j in range(6)]), axis=3)                                           # (A^T M) A: 4 x 4
+    Y = Y + bias[None, :, None, None]
+    got = np.maximum(Y, np.float32(0.1) * Y)
+    want = np.zeros((cout, 4 * th, 4 * tw))
+    for ky in range(3):
+        for kx in range(3):
+            want += np.einsum("pc,cyx->pyx", w[:, :, ky, kx].astype(np.float64), x[:, ky:ky + 4 * th, kx:kx + 4 * tw].astype(np.float64))
+    want += bias[:, None, None]
+    want = np.maximum(want, 0.1 * want)
+    got_img = got.reshape(th, tw, cout, 4, 4).transpose(2, 0, 3, 1, 4).reshape(cout, 4 * th, 4 * tw)
+    err = np.abs(got_img - want)
+    gate = 1e-5 + 1e-4 * np.abs(want)
+    worst = (err / gate).max()
+    assert worst <= 1.0, "worst |error| / gate = %.2f" % worst
