@@ -87,8 +87,12 @@ typedef struct w2xc_opts {
                                * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
     int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path (the one-plane last layer inside the epilogue
                                * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  Results stay
-                               * inside the fp32 gate either way (tests/test_gpu_winograd.py); W2XC_FUSION_AUTO = on unless the
-                               * environment says W2XC_FUSE_LAST_FP32=0.  (The 16-bit modes: W2XC_SPLIT_FUSE_FIRST / _LAST.) */
+                               * inside the fp32 gate either way (tests/test_gpu_winograd.py).  The epilogue exists in
+                               * conv3x3_wino16: W2XC_FUSION_AUTO fuses where the layer before the last runs that kernel
+                               * (W2XC_KERNEL_WINOGRAD; environment W2XC_FUSE_LAST_FP32=0 turns it off) -- not under the
+                               * default conv3x3_wino4, whose frame is faster unfused; W2XC_FUSION_ON with
+                               * W2XC_KERNEL_AUTO runs that one layer on conv3x3_wino16 to fuse.
+                               * (The 16-bit modes: W2XC_SPLIT_FUSE_FIRST / _LAST.) */
 } w2xc_opts;
 
 #define W2XC_FUSION_AUTO 0
