@@ -1,5 +1,5 @@
 import sys; sys.path.insert(0, "/root/repo")
-import numpy as np, torch
+import torch
 import __graft_entry__ as g
 from tools import gen_model
 w = g.load_package()

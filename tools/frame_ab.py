@@ -3,7 +3,6 @@
 process (boxes differ by 2-4 %): w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD32 / _WINOGRAD.
    python tools/frame_ab.py [--kernels wino16,wino32,mfma] [--rounds 3] [--steps 5] [--topo 1,32,32,64,64,128,128,1]"""
 import argparse, os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as graft

@@ -1,4 +1,4 @@
-import os, sys, time
+import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import __graft_entry__ as g

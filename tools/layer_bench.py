@@ -2,7 +2,6 @@
 """Time ONE mid layer (cin->cout) on the GPU: model 1->cin->cout->1, per-layer hipEvent times.
    W2XC_MFMA_VARIANT=<n> python tools/layer_bench.py --cin 128 --cout 128"""
 import argparse, os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as graft

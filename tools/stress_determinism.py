@@ -4,7 +4,6 @@ the scale2.0x and the noise topologies, full-frame and odd sizes): the kernels a
 construction, so (1) repeated runs on the same input must be bit-identical, (2) under concurrent load on a
 second stream too.  A DMA that lands late or a buffer overwritten early shows up as differing tiles."""
 import os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as graft

@@ -3,10 +3,9 @@ single-layer standard-normal case of tests/test_gpu_parity.py::test_layer_filter
 (|x - oracle32| <= 1e-4 |oracle32| + 1e-5; 'gate use' = the largest ratio, 1.0 = at the gate).  numpy only (CPU):  python tools/winograd_points.py
 Result (round 3): Lavin & Gray's 0, +-1, +-2 -> 9.5e-6 of the range / gate use 1.34 (FAILS); 0, +-1/2, +-3/2 -> 3.0e-6 / 0.56 with the same operation count
 (symmetric point pairs) -- the points conv3x3_wino4 uses."""
-import numpy as np, sys, itertools
+import numpy as np, sys
 sys.path.insert(0,'/root/repo')
 from tools import gen_model
-from fractions import Fraction as F
 def cook_toom(points, m=4, r=3):
     n = m + r - 1
     a = [float(p) for p in points]           # n-1 finite points, plus infinity
