@@ -64,6 +64,15 @@ static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned v
                  : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
                  : "memory", "m0");
 }
+// the same with the LDS address as (wave-uniform base + compile-time offset): no SGPR per destination for the compiler to hoist and keep alive
+template <unsigned LDS_IMM>
+static __device__ __forceinline__ void lds_dma16_si(const void *sbase, unsigned voff, unsigned lds_base)
+{
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
+                 : "memory", "m0", "scc");
+}
 #define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // s_waitcnt vmcnt(n) for an n that constant-folds after unrolling; the queue holds at most 63 entries
 static __device__ __forceinline__ void wait_vmcnt_n(int n)

@@ -85,6 +85,9 @@ bool w2xc_wino16_supported(int cin, int cout);
 bool w2xc_wino4_supported(int cin, int cout);
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
+// the same on PLANAR activations, transform in two phases (w2xc_wino4p.hip): in_ps = 1 / in_cs = plane stride; out planar (out_ps = 1) or NHWC (out_cs = 1)
+bool w2xc_wino4p_supported(int cin, int cout);
+hipError_t w2xc_launch_wino4p(const W2xcConvDesc &d, hipStream_t stream);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,
@@ -110,6 +113,10 @@ hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, long long s_cs,
                               float *dst, long long d_rs, long long d_ps, long long d_cs,
                               int h, int w, int c, hipStream_t stream);
+
+// replicate-padded planar copy (Model::filter's BORDER_REPLICATE made explicit for conv3x3_wino4p): dst is (h + 2 pad) x (w + 2 pad) per plane
+hipError_t w2xc_launch_pad_planar(const float *src, long long s_rs, long long s_ps, long long s_cs, float *dst, long long d_rs, long long d_cs,
+                                  int h, int w, int c, int pad, hipStream_t stream);
 
 // N2 (w2xc_color.hip): colour front/back end and U/V bicubic of the CLI scale loop (main.cpp:74-76,144,171-172)
 hipError_t w2xc_launch_u8_to_yuv(const unsigned char *src, size_t stride, int w, int h, float *y, float *u, float *v, hipStream_t st);

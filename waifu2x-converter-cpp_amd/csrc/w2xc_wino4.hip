@@ -457,36 +457,6 @@ bool w2xc_wino4_supported(int cin, int cout)
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
 }
 
-// wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = 6 i + j,
-// U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
-void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
-{
-    static const double GM[6][3] = {{64.0 / 81, 0, 0},
-                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27},
-                                    {-128.0 / 243, 32.0 / 81, -8.0 / 27},
-                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},
-                                    {32.0 / 243, -16.0 / 81, 8.0 / 27},
-                                    {0, 0, 1}};
-    const int nst = cin / 4, nob = cout / 64;
-    for (int ob = 0; ob < nob; ob++)
-        for (int s = 0; s < nst; s++)
-            for (int pt = 0; pt < 4; pt++)
-                for (int k = 0; k < 4; k++)
-                    for (int o = 0; o < 16; o++) {
-                        const int plane = 64 * ob + 16 * pt + o, c = 4 * s + k;
-                        const float *g = w + ((size_t)plane * cin + c) * 9;
-                        double tmp[6][3];
-                        for (int i = 0; i < 6; i++)
-                            for (int j = 0; j < 3; j++) tmp[i][j] = GM[i][0] * g[0 * 3 + j] + GM[i][1] * g[1 * 3 + j] + GM[i][2] * g[2 * 3 + j];
-                        for (int i = 0; i < 6; i++)
-                            for (int j = 0; j < 6; j++) {
-                                const double u = tmp[i][0] * GM[j][0] + tmp[i][1] * GM[j][1] + tmp[i][2] * GM[j][2];
-                                const int xi = i * 6 + j;
-                                dst[(((((size_t)ob * nst + s) * 9 + (xi >> 2)) * 4 + pt) * 64 + k * 16 + o) * 4 + (xi & 3)] = (float)u;
-                            }
-                    }
-}
-
 template <int CIN, int COUT>
 static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 {

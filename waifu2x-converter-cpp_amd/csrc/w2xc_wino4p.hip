@@ -1,0 +1,555 @@
+// w2xc_wino4p.hip -- conv3x3_wino4p: the 3x3 x Cin x Cout contraction of Model::filterWorker
+// (/root/reference/src/modelHandler.cpp:117-159) as Winograd F(4x4, 3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD,
+// on PLANAR activations (one H x W fp32 plane per channel -- the reference's own std::vector<cv::Mat> layout).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 4x4 output block and 6x6 input patch: 36 positions xi of the transformed domain =
+//   36 independent GEMMs  M_xi[o][t] = sum_c U_xi[o][c] V_xi[c][t]  (o = output plane, t = block, c = input plane): 2.25 multiplies
+//   per output.  fp32 throughout; Cook-Toom on the points 0, +-3/4, +-3/2, inf (tools/winograd_points.py: every entry a dyadic rational):
+//     B^T = [81/64 0 -45/16 0 1 0; 0 -27/16 -9/4 3/4 1 0; 0 27/16 -9/4 -3/4 1 0; 0 -27/32 -9/16 3/2 1 0; 0 27/32 -9/16 -3/2 1 0; 0 81/64 0 -45/16 0 1]
+//     G   = [64/81 0 0; -128/243 -32/81 -8/27; -128/243 32/81 -8/27; 32/243 16/81 8/27; 32/243 -16/81 8/27; 0 0 1]
+//     A^T = [1 1 1 1 1 0; 0 3/4 -3/4 3/2 -3/2 0; 0 9/16 9/16 9/4 9/4 0; 0 27/64 -27/64 27/8 -27/8 1]
+//
+//   Work item  16 rows x 32 pixels of output (4 x 8 blocks of 4x4) x 64 output planes.  8 waves: wave (bt, pt) owns block tile bt
+//              (block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
+//   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave, both operands from LDS in fragment order
+//              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand; A = U, lane = 16 k + o; B = V, lane = 16 k + t).
+//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS -- in TWO PHASES over two stages,
+//              so that every SIMD carries half a transform in every stage (a whole transform in one stage left the transforming wave
+//              alone on its SIMD for half of it: 4400-cycle stages where the MFMAs need 2304, round 3):
+//                phase A (stage g, for stage g + 2): 6 x (ds_read_b128 + ds_read_b64) of the raw tile, B^T d down the columns (84 VALU),
+//                         the 36 intermediate values PARKED in the V slot of stage g + 2 at the lane's own nine quads (lane-private);
+//                phase B (stage g + 1): the nine quads back, (.) B along the rows (84 VALU), the final V to the same addresses.
+//              Wave (bt, pt) transforms block tile bt for the stages g' = pt + 2 bt (mod 4): in every stage the four transforming waves
+//              (two in phase A, two in phase B) sit on four different SIMDs.  Nothing of a transform lives in registers across a stage
+//              boundary or an epilogue.  V is a ring of three slots (read g | final g + 1 | parked g + 2).
+//   LDS        raw[3] x 11 KiB: the 18 x 36 pixel halo tile of a 4-channel slice as 16-byte chunks (channel kk, row R, pixel quad q) at
+//              chunk index kk * 168 + R * 9 + q -- the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free;
+//              U[2] x 36 KiB + V[3] x 18 KiB + bias = 159.5 KiB.
+//   Transfers  LDS-DMA (global_load_lds_dwordx4), SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead) and 11 raw
+//              pieces (four stages ahead: phase A of stage g + 2 reads them, the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four consecutive pixels of one
+//              plane row: whole 128-byte lines from HBM, where the NHWC tile of round 3 pulled a 128-byte line per 32 bytes used.
+//   Epilogue   Y = A^T M A per output-row pair, bias, LeakyReLU; planar out: one 16-byte store = four pixels of a plane row, 8 lanes = one
+//              128-byte line (NHWC out, for a consumer that wants it: one store = a pixel's four planes).
+//   Edges      rows are clamped (replicate) in the transfer addresses; patch columns >= in_w are ZEROED in phase A (they only reach
+//              outputs >= out_w, and what is in memory there is not defined): results do not depend on memory contents outside the plane.
+//   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4); run_rows' four-rows-per-layer
+//              band geometry makes every region edge that is not a plane edge a block edge: bit-identical results across bandings.
+#include "w2xc_kernels.h"
+#include "w2xc_device.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <type_traits>
+
+#ifdef W4_TIMING
+// tools/ubench/wino4p_timing.hip: s_memtime stamps of waves 0 and 4 of workgroup 0 -- per stage (before the closing wait, after it, after the
+// barrier) and after every epilogue -- [wave >> 2][index]
+__device__ unsigned long long w4_stamps[2][8192];
+#define W4_STAMP(idx) do { const int i_ = (idx); if (blockIdx.x == 0 && pt == 0 && lane == 0 && i_ < 8192) w4_stamps[bt][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(idx) do { } while (0)
+#endif
+#ifndef W4P_PRIO
+#define W4P_PRIO 0   // experiment: s_setprio of a wave inside the stages that carry its transform work
+#endif
+#ifndef W4_ABL
+#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores
+#endif
+
+namespace {
+
+// y = B^T x for a 6-vector, in place (14 fma / mul / add)
+static __device__ __forceinline__ void bt6(float &x0, float &x1, float &x2, float &x3, float &x4, float &x5)
+{
+    const float y0 = __builtin_fmaf(-2.8125f, x2, __builtin_fmaf(1.265625f, x0, x4));
+    const float p = __builtin_fmaf(-2.25f, x2, x4), q = __builtin_fmaf(-1.6875f, x1, 0.75f * x3);
+    const float u = __builtin_fmaf(-0.5625f, x2, x4), v = __builtin_fmaf(-0.84375f, x1, 1.5f * x3);
+    const float y5 = __builtin_fmaf(-2.8125f, x3, __builtin_fmaf(1.265625f, x1, x5));
+    x0 = y0;
+    x1 = p + q;
+    x2 = p - q;
+    x3 = u + v;
+    x4 = u - v;
+    x5 = y5;
+}
+
+// y = A^T m for a 6-vector (12 fma / mul / add)
+static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2, float &y3)
+{
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = __builtin_fmaf(1.5f, d2, 0.75f * d1);
+    y2 = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
+    y3 = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+}   // namespace
+
+template <int CIN, int COUT, bool OUT_PLANAR>
+__global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int tiles_x, int nitems)
+{
+    constexpr int ROWS = 16;
+    constexpr int NST = CIN / 4;                            // stages (4-channel slices) per item
+    constexpr int NOB = COUT / 64;                          // 64-plane blocks
+    constexpr int CHS = 168;                                // chunks per channel of a raw buffer (18 rows x 9 quads = 162, + 6: stride = 8 mod 16)
+    constexpr int RAW_PIECES = 11;                          // 4 x 168 = 672 chunks = 10.5 pieces of 64 x 16 bytes
+    constexpr unsigned RAW_BYTES = RAW_PIECES * 1024;
+    constexpr unsigned U_BASE = 3 * RAW_BYTES, U_BYTES = 36 * 1024;
+    constexpr unsigned V_BASE = U_BASE + 2 * U_BYTES, V_BYTES = 18 * 1024;
+    constexpr unsigned BIAS_BASE = V_BASE + 3 * V_BYTES;
+    static_assert(CIN % 16 == 0 && COUT % 64 == 0 && NST % 4 == 0 && NST >= 8, "planes");
+    constexpr int STRIP = 16;
+    const int tiles_y = nitems / (NOB * tiles_x);
+    auto tile_coords = [&](int pt_, int &ty_, int &tx_) {     // strips of 16 tiles, row by row inside a strip (the next round of an XCD is the tile row below)
+        const int per_strip = STRIP * tiles_y;
+        int sidx = pt_ / per_strip;
+        const int nfull = tiles_x / STRIP;
+        if (sidx > nfull) sidx = nfull;
+        const int wid = sidx < nfull ? STRIP : tiles_x - nfull * STRIP;
+        const int q = pt_ - sidx * per_strip;
+        ty_ = q / wid;
+        tx_ = sidx * STRIP + (q - ty_ * wid);
+    };
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    char *ldsb = reinterpret_cast<char *>(lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pt = wave & 3, bt = wave >> 2;
+    const int t = lane & 15, k = lane >> 4;
+
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int cq = nitems >> 3, cr = nitems & 7;
+    const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
+    const int item0 = chunk_begin + (blockIdx.x >> 3);
+    if (item0 >= chunk_end) return;
+    const int nmy = (chunk_end - item0 + per - 1) / per;
+    auto item_of = [&](int n) { return item0 + (n < nmy ? n : nmy - 1) * per; };
+
+    for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
+
+    // ---- raw tile transfers: chunk ci = piece * 64 + lane -> (channel kk, row R, quad q); wave w sends pieces w and (w < 3) 8 + w ----
+    const long long cs4 = d.in_cs * 4, rs4 = d.in_rs * 4;     // bytes
+    unsigned voff[2];
+    const char *a_base;
+    int xlim_r;                                                // in_w - x0 of the tile the raw cursor is in (patch columns >= it are outside the plane)
+    auto tile_offsets = [&](int it) {
+        int ty_, tx_;
+        tile_coords(it / NOB, ty_, tx_);
+        const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
+        const int yb = clampi(y0, 0, d.in_h - 1);
+        a_base = reinterpret_cast<const char *>(d.in) + (long long)yb * rs4;
+        xlim_r = d.in_w - x0;
+        const int xq_last = (d.in_w - 1) & ~3;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int ci = (jj * 8 + wave) * 64 + lane;
+            int kk = ci / CHS;
+            kk = kk < 4 ? kk : 3;
+            const int rem = ci - kk * CHS;
+            int R = rem / 9;
+            const int q = rem - R * 9;
+            R = R < ROWS + 2 ? R : ROWS + 1;
+            const int gy = clampi(y0 + R, 0, d.in_h - 1) - yb;
+            int gx = x0 + 4 * q;
+            gx = gx < xq_last ? gx : xq_last;
+            voff[jj] = (unsigned)((long long)kk * cs4 + (long long)gy * rs4 + (long long)gx * 4);
+        }
+    };
+    // LDS destinations of the transfers are (wave base + immediate): as precomputed wave-uniform values the ~50 of them are hoisted out of the loops
+    // and the SGPR file overflows into VGPR lanes and scratch
+    const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    // raw piece jj * 8 + wave of 4-channel slice `slice` of the tile a_base / voff describe, into the raw buffer at byte offset roff
+    auto dma_raw = [&](auto JJ, unsigned roff, int slice) {
+        constexpr int jj = decltype(JJ)::value;
+        const char *sbase = a_base + (long long)slice * (4 * cs4);
+        lds_dma16_si<jj * 8192u>(sbase, voff[jj], wbase + roff);
+    };
+    // U of (64-plane block ob, stage s_): 36 pieces of 1 KiB (one per xi); wave w sends xi = w, w + 8, w + 16, w + 24 and (w < 4) 32 + w
+    const unsigned b_voff = (unsigned)lane * 16u;
+    const char *wpk_w = reinterpret_cast<const char *>(d.wpk) + (size_t)wave * 1024;
+    auto dma_u = [&](int ob, int s_, auto SLOT, auto Q) {     // piece xi = 8 q + wave
+        constexpr unsigned slot = decltype(SLOT)::value;
+        constexpr int q = decltype(Q)::value;
+        const char *sbase = wpk_w + ((size_t)(ob * NST + s_) * 36 + q * 8) * 1024;
+        lds_dma16_si<U_BASE + slot * U_BYTES + q * 8192u>(sbase, b_voff, wbase);
+    };
+
+    // ---- addressing ----
+    // MFMA operands: lane-linear dwords
+    const unsigned ua0 = U_BASE + (unsigned)pt * 1024u + (unsigned)lane * 16u;    // + slot * U_BYTES + (xi / 4) * 4096: four xi per b128
+    const unsigned va0 = V_BASE + (unsigned)bt * 1024u + (unsigned)lane * 16u;    // + slot * V_BYTES + (xi / 4) * 2048
+    // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch row i, columns 0..3 = chunk (kk, 4 (2 bt + r) + i, c),
+    // columns 4, 5 = the first half of chunk (kk, same row, c + 1)
+    const int tr_r = lane >> 5, tr_k = (lane >> 3) & 3, tr_c = lane & 7;
+    const unsigned tr_rd = (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);               // + buffer + i * 144 (+ 16)
+    const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);  // + slot * V_BYTES + (xi / 4) * 2048
+
+    float dd[36];
+    // (indices arrive as integral constants: register arrays indexed through a run-time lambda parameter end up in scratch)
+    auto pa_read = [&](const char *src, auto I) {               // patch row i
+        constexpr int i = decltype(I)::value;
+        if constexpr ((W4_ABL & 2) != 0) {
+            static_for<0, 6>([&](auto JJ) { dd[i * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + i * 144);
+            const f32x2 b = *reinterpret_cast<const f32x2 *>(src + i * 144 + 16);
+            dd[i * 6 + 0] = a[0]; dd[i * 6 + 1] = a[1]; dd[i * 6 + 2] = a[2]; dd[i * 6 + 3] = a[3];
+            dd[i * 6 + 4] = b[0]; dd[i * 6 + 5] = b[1];
+        }
+    };
+    auto pa_mask = [&](int xlim) {                               // patch columns outside the plane: zero (wave-uniform test first)
+        if (xlim < 34) {
+            const int lim = xlim - 4 * tr_c;
+            static_for<0, 36>([&](auto E) {
+                constexpr int e = decltype(E)::value;
+                dd[e] = (e % 6) < lim ? dd[e] : 0.0f;
+            });
+        }
+    };
+    auto tr_col = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
+    };
+    auto quad_write = [&](char *dst, auto Q4) {
+        constexpr int q4 = decltype(Q4)::value;
+        if constexpr (!(W4_ABL & 2)) *reinterpret_cast<f32x4 *>(dst + q4 * 2048) = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
+    };
+    auto quad_read = [&](const char *src, auto Q4) {
+        constexpr int q4 = decltype(Q4)::value;
+        if constexpr ((W4_ABL & 2) != 0) {
+            dd[4 * q4] = dd[4 * q4 + 1] = dd[4 * q4 + 2] = dd[4 * q4 + 3] = (float)q4;
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + q4 * 2048);
+            dd[4 * q4] = a[0]; dd[4 * q4 + 1] = a[1]; dd[4 * q4 + 2] = a[2]; dd[4 * q4 + 3] = a[3];
+        }
+    };
+    auto tr_row = [&](char *dst, auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
+        // the quads of four consecutive xi that this row completes: 4 q + 3 <= 6 i + 5 and not already complete after row i - 1
+        static_for<(i == 0 ? 0 : (6 * i - 4) / 4 + 1), (6 * i + 2) / 4 + 1>([&](auto Q4) { quad_write(dst, Q4); });
+    };
+
+    // Wave (bt, pt) transforms for the stages g' = pt + 2 bt (mod 4): phase A in stage g' - 2, phase B in stage g' - 1.  With PH = (pt - 2 bt) mod 4
+    // its roles inside a group of four stages (global stage count mod 4 = j) are fixed at compile time -- a run-time "is it my turn" around the stage
+    // bodies joins 144 accumulators in phi nodes and the register allocator gives up -- so the item loop exists four times and a wave picks its copy once.
+    auto run = [&](auto PH_) {
+    constexpr int PH = decltype(PH_)::value;
+    // ---- prologue: raw slices 0, 1 and U(stage 0) of the first item; V(stage 0) whole, phase A of V(stage 1); raw slice 2 ----
+    tile_offsets(item_of(0));
+    int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using U0 = std::integral_constant<unsigned, 0u>;
+    using U1 = std::integral_constant<unsigned, 1u>;
+    for (int sl = 0; sl < 3; sl++) {
+        dma_raw(C0{}, (unsigned)sl * RAW_BYTES, sl);
+        if (wave < 3) dma_raw(C1{}, (unsigned)sl * RAW_BYTES, sl);
+    }
+    {
+        const int ob0 = item_of(0) % NOB;
+        static_for<0, 4>([&](auto Q) { dma_u(ob0, 0, U0{}, Q); });
+        if (wave < 4) dma_u(ob0, 0, U0{}, std::integral_constant<int, 4>{});
+    }
+    W2XC_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (PH == 0 || PH == 1) {
+        const char *src = ldsb + PH * RAW_BYTES + tr_rd;
+        char *dst = ldsb + tr_wr + PH * V_BYTES;
+        static_for<0, 6>([&](auto I) { pa_read(src, I); });
+        pa_mask(xlim_cur);
+        static_for<0, 6>([&](auto J) { tr_col(J); });
+        if constexpr (PH == 0) static_for<0, 6>([&](auto I) { tr_row(dst, I); });
+        else static_for<0, 9>([&](auto Q4) { quad_write(dst, Q4); });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_raw(C0{}, 0u, 3);   // (waited for by the first stage's closing wait: phase A of the second stage reads it)
+    if (wave < 3) dma_raw(C1{}, 0u, 3);
+
+    unsigned v0 = 0, v1 = V_BYTES, v2 = 2 * V_BYTES;   // byte offsets of the V slots of stages g, g + 1, g + 2
+    unsigned r0 = 0, r1 = RAW_BYTES, r2 = 2 * RAW_BYTES;   // ... of the raw buffers of the slices of stages g (= g + 3), g + 1 (= g + 4: this stage's transfer), g + 2 (phase A reads it)
+    int stamp = 0;
+    (void)stamp;
+    W4_STAMP(stamp++);
+    for (int n = 0; n < nmy; n++) {
+        const int item = item_of(n), item_n = item_of(n + 1);
+        f32x4 acc[36];
+#pragma unroll
+        for (int xi = 0; xi < 36; xi++) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+        // one stage; J = global stage count mod 4 (NST is a multiple of 4: = s mod 4)
+        auto stage = [&](auto J_, int s) {
+            constexpr int J = decltype(J_)::value;
+            constexpr int role = J == ((PH + 2) & 3) ? 1 : J == ((PH + 3) & 3) ? 2 : 0;   // 1 = phase A (for stage g + 2), 2 = phase B (for stage g + 1)
+            constexpr unsigned par = J & 1, nxt = par ^ 1u;                               // U slot of this stage / the next; raw buffer of stage g + 2 = par
+            int u_ob = item % NOB, u_s = s + 1;
+            if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
+            const char *ua = ldsb + ua0 + par * U_BYTES;
+            const char *va = ldsb + va0 + v0;
+            const char *srcA = ldsb + r2 + tr_rd;
+            char *dstA = ldsb + tr_wr + v2;
+            char *dstB = ldsb + tr_wr + v1;
+            const int xlimA = s + 2 < NST ? xlim_cur : xlim_r;
+            if constexpr (J == 0) {
+                if (s == NST - 4) tile_offsets(item_n);   // from this stage on the raw cursor (four stages ahead) is in the next item's tile
+            }
+            const int r_slice = s + 4 < NST ? s + 4 : s + 4 - NST;
+            // operands of four xi per ds_read_b128; the quads of the next four xi are read while these four multiply
+            f32x4 a4[2], b4[2];
+            if constexpr (role != 0 && W4P_PRIO != 0) __builtin_amdgcn_s_setprio(W4P_PRIO);
+            a4[0] = *reinterpret_cast<const f32x4 *>(ua);
+            b4[0] = *reinterpret_cast<const f32x4 *>(va);
+            static_for<0, 36>([&](auto XI) {
+                constexpr int xi = decltype(XI)::value;
+                if constexpr ((xi & 3) == 0 && xi + 4 < 36) {
+                    a4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + 1) * 4096);
+                    b4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + 1) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) & 1][xi & 3], b4[(xi >> 2) & 1][xi & 3], acc[xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // transfers, early in the stage: everything is waited for at its end
+                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
+                    dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 9 && !(W4_ABL & 16)) {
+                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 11 && !(W4_ABL & 32)) {
+                    dma_raw(C0{}, r1, r_slice);                // slice of stage g + 4 into the buffer phase A of stage g - 1 has read
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 13 && !(W4_ABL & 32)) {
+                    if (wave < 3) dma_raw(C1{}, r1, r_slice);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (role == 1) {
+                    if constexpr (xi < 2) {
+                        pa_read(srcA, std::integral_constant<int, 3 * xi>{});
+                        pa_read(srcA, std::integral_constant<int, 3 * xi + 1>{});
+                        pa_read(srcA, std::integral_constant<int, 3 * xi + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi >= 4 && xi < 10) {
+                        if constexpr (xi == 4) pa_mask(xlimA);
+                        tr_col(std::integral_constant<int, xi - 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi >= 10 && xi < 13) {
+                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10)>{});
+                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10) + 1>{});
+                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10) + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (role == 2) {
+                    if constexpr (xi < 3) {
+                        quad_read(dstB, std::integral_constant<int, 3 * xi>{});
+                        quad_read(dstB, std::integral_constant<int, 3 * xi + 1>{});
+                        quad_read(dstB, std::integral_constant<int, 3 * xi + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi >= 4 && xi < 10) {
+                        tr_row(dstB, std::integral_constant<int, xi - 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+            if constexpr (role != 0 && W4P_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+            W4_STAMP(stamp++);
+            // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
+            // transfers -- may still fly
+            if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
+            else if (wave < 3) W2XC_WAIT_VMCNT(2);
+            else W2XC_WAIT_VMCNT(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_STAMP(stamp++);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            { const unsigned tv = v0; v0 = v1; v1 = v2; v2 = tv; }
+            { const unsigned tr = r0; r0 = r1; r1 = r2; r2 = tr; }
+            W4_STAMP(stamp++);
+        };
+#pragma unroll 1
+        for (int s = 0; s < NST; s += 4) {
+            stage(std::integral_constant<int, 0>{}, s);
+            stage(std::integral_constant<int, 1>{}, s + 1);
+            stage(std::integral_constant<int, 2>{}, s + 2);
+            stage(std::integral_constant<int, 3>{}, s + 3);
+        }
+        xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile three stages ago)
+        {
+            // ---- epilogue: Y = A^T M A, bias, LeakyReLU, stores.  C/D of the 16x16 MFMA: lane & 15 = block, register e = plane
+            //      4 (lane >> 4) + e of the plane tile ----
+            __builtin_amdgcn_s_setprio(2);
+            const int ob = item % NOB;
+            int tile_y, tile_x;
+            tile_coords(item / NOB, tile_y, tile_x);
+            const int ty0 = tile_y * ROWS - d.wino_py;
+            const int oy = ty0 + 4 * (2 * bt + (t >> 3)), ox = tile_x * 32 + 4 * (t & 7);
+            const int plane0 = ob * 64 + pt * 16 + 4 * k;
+            float *obase = OUT_PLANAR ? d.out + (long long)plane0 * d.out_cs + (long long)oy * d.out_rs + ox
+                                      : d.out + (long long)oy * d.out_rs + (long long)ox * COUT + plane0;
+            const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + plane0 * 4);
+            // Two output ROWS of the block at a time (the row transform of a column per row PAIR: 7 operations instead of 10 for all four rows):
+            // 48 + 16 live values beside the 144 accumulators.
+#pragma unroll
+            for (int rp = 0; rp < 2; rp++) {
+                float tm[2][6][4];   // [row of the pair][column j][plane e]
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const float m0 = acc[0 * 6 + j][e], m1 = acc[1 * 6 + j][e], m2 = acc[2 * 6 + j][e], m3 = acc[3 * 6 + j][e], m4 = acc[4 * 6 + j][e],
+                                    m5 = acc[5 * 6 + j][e];
+                        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                        if (rp == 0) {
+                            tm[0][j][e] = m0 + s1 + s2;
+                            tm[1][j][e] = __builtin_fmaf(1.5f, d2, 0.75f * d1);
+                        } else {
+                            tm[0][j][e] = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
+                            tm[1][j][e] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
+                        }
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int i = 2 * rp + rr;
+                    f32x4 y[4];      // OUT_PLANAR: y[e] = the four pixels of row i of plane e; NHWC: y[j] = the four planes of pixel j
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float y0, y1, y2, y3;
+                        at6(tm[rr][0][e], tm[rr][1][e], tm[rr][2][e], tm[rr][3][e], tm[rr][4][e], tm[rr][5][e], y0, y1, y2, y3);
+                        const float w0 = y0 + bq[e], w1 = y1 + bq[e], w2 = y2 + bq[e], w3 = y3 + bq[e];
+                        const float l0 = __builtin_amdgcn_fmed3f(w0, 0.1f * w0, 3.402823466e+38f), l1 = __builtin_amdgcn_fmed3f(w1, 0.1f * w1, 3.402823466e+38f);
+                        const float l2 = __builtin_amdgcn_fmed3f(w2, 0.1f * w2, 3.402823466e+38f), l3 = __builtin_amdgcn_fmed3f(w3, 0.1f * w3, 3.402823466e+38f);
+                        if constexpr (OUT_PLANAR) y[e] = f32x4{l0, l1, l2, l3};
+                        else { y[0][e] = l0; y[1][e] = l1; y[2][e] = l2; y[3][e] = l3; }
+                    }
+                    if constexpr ((W4_ABL & 64) != 0) {
+                        if (y[0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0] + y[1] + y[2] + y[3];
+                    } else if constexpr (OUT_PLANAR) {
+                        // whole quads: the row stride holds roundup4(out_w) pixels (the launcher checks), columns >= out_w are never read as data
+                        if (interior || (oy + i >= 0 && oy + i < d.out_h && ox < d.out_w)) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) *reinterpret_cast<f32x4 *>(obase + (long long)e * d.out_cs + (long long)i * d.out_rs) = y[e];
+                        }
+                    } else if (interior) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT) = y[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (oy + i >= 0 && oy + i < d.out_h && ox + j < d.out_w) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT) = y[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            W4_STAMP(stamp++);
+        }
+    }
+    W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
+    };
+    switch ((pt - 2 * bt) & 3) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool w2xc_wino4p_supported(int cin, int cout)
+{
+    return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+}
+
+// wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = 6 i + j,
+// U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
+void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
+{
+    static const double GM[6][3] = {{64.0 / 81, 0, 0},
+                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27},
+                                    {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},
+                                    {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                    {0, 0, 1}};
+    const int nst = cin / 4, nob = cout / 64;
+    for (int ob = 0; ob < nob; ob++)
+        for (int s = 0; s < nst; s++)
+            for (int pt = 0; pt < 4; pt++)
+                for (int k = 0; k < 4; k++)
+                    for (int o = 0; o < 16; o++) {
+                        const int plane = 64 * ob + 16 * pt + o, c = 4 * s + k;
+                        const float *g = w + ((size_t)plane * cin + c) * 9;
+                        double tmp[6][3];
+                        for (int i = 0; i < 6; i++)
+                            for (int j = 0; j < 3; j++) tmp[i][j] = GM[i][0] * g[0 * 3 + j] + GM[i][1] * g[1 * 3 + j] + GM[i][2] * g[2 * 3 + j];
+                        for (int i = 0; i < 6; i++)
+                            for (int j = 0; j < 6; j++) {
+                                const double u = tmp[i][0] * GM[j][0] + tmp[i][1] * GM[j][1] + tmp[i][2] * GM[j][2];
+                                const int xi = i * 6 + j;
+                                dst[(((((size_t)ob * nst + s) * 9 + (xi >> 2)) * 4 + pt) * 64 + k * 16 + o) * 4 + (xi & 3)] = (float)u;
+                            }
+                    }
+}
+
+template <int CIN, int COUT, bool OUT_PLANAR>
+static hipError_t launch_wino4p(const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 3) + 15) / 16;
+    const int nitems = tiles_x * tiles_y * (COUT / 64);
+    constexpr size_t lds_bytes = 3 * (size_t)(11 * 1024) + 2 * (size_t)(36 * 1024) + 3 * (size_t)(18 * 1024) + COUT * 4;   // raw + U + V + bias
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_wino4p<CIN, COUT, OUT_PLANAR>;
+    static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev < 64) attr_done.fetch_or(1ull << dev);
+    }
+    int grid = 256;   // one persistent workgroup per CU; a multiple of 8 (one share per XCD)
+    if (grid > ((nitems + 7) & ~7)) grid = (nitems + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, d, tiles_x, nitems);
+    return hipGetLastError();
+}
+
+// d.wpk = w2xc_wino4_pack image; planar fp32 in (in_ps = 1, in_cs = plane stride), planar (out_ps = 1) or NHWC (out_cs = 1, out_ps = cout) out;
+// d.wino_py = first output row mod 4; off_x a multiple of 4 (the engine's layers: 0)
+hipError_t w2xc_launch_wino4p(const W2xcConvDesc &d, hipStream_t stream)
+{
+    if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
+    if (d.in_ps != 1 || d.in_shift != 0 || (d.in_rs & 3) != 0 || (d.in_cs & 3) != 0 || (((size_t)d.in) & 15) != 0) return hipErrorInvalidValue;
+    if (d.off_x < 0 || (d.off_x & 3) != 0 || d.in_rs < ((d.in_w + 3) & ~3)) return hipErrorInvalidValue;
+    if (3 * d.in_cs * 4 + 24 * d.in_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit lane offsets inside a 4-channel slice of a tile
+    const bool planar = d.out_ps == 1;
+    if (planar) {
+        if ((d.out_rs & 3) != 0 || (d.out_cs & 3) != 0 || (((size_t)d.out) & 15) != 0 || d.out_rs < ((d.out_w + 3) & ~3)) return hipErrorInvalidValue;
+    } else if (d.out_ps != d.cout || d.out_cs != 1 || (d.out_rs & 3) != 0 || (((size_t)d.out) & 15) != 0) return hipErrorInvalidValue;
+#ifdef W4P_SINGLE   // (development builds: one instantiation)
+    return planar && d.cin == 128 && d.cout == 128 ? launch_wino4p<128, 128, true>(d, stream) : hipErrorInvalidValue;
+#else
+    switch (d.cin * 1000 + d.cout) {
+    case 32064:  return planar ? launch_wino4p<32, 64, true>(d, stream) : launch_wino4p<32, 64, false>(d, stream);
+    case 32128:  return planar ? launch_wino4p<32, 128, true>(d, stream) : launch_wino4p<32, 128, false>(d, stream);
+    case 64064:  return planar ? launch_wino4p<64, 64, true>(d, stream) : launch_wino4p<64, 64, false>(d, stream);
+    case 64128:  return planar ? launch_wino4p<64, 128, true>(d, stream) : launch_wino4p<64, 128, false>(d, stream);
+    case 128064: return planar ? launch_wino4p<128, 64, true>(d, stream) : launch_wino4p<128, 64, false>(d, stream);
+    case 128128: return planar ? launch_wino4p<128, 128, true>(d, stream) : launch_wino4p<128, 128, false>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+#endif
+}
