@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     for (auto &v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
     for (int o = 0; o < cout; o++) hb[o] = 0.01f * (float)(o % 7) - 0.02f;
     std::vector<float> pk((size_t)36 * cin * cout);
-    w2xc_wino4_pack(cin, cout, hw.data(), pk.data());
+    w2xc_wino4p_pack(cin, cout, hw.data(), pk.data());
     float *din, *dout, *dw, *dwraw, *db;
     const size_t out_floats = nhwc_out ? (size_t)h * w * cout : (size_t)ocs_p * cout;
     hipMalloc(&din, hin.size() * 4); hipMalloc(&dout, out_floats * 4); hipMalloc(&dw, pk.size() * 4); hipMalloc(&db, cout * 4); hipMalloc(&dwraw, hw.size() * 4);

@@ -87,6 +87,7 @@ void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
 // the same on PLANAR activations, transform in two phases (w2xc_wino4p.hip): in_ps = 1 / in_cs = plane stride; out planar (out_ps = 1) or NHWC (out_cs = 1)
 bool w2xc_wino4p_supported(int cin, int cout);
+void w2xc_wino4p_pack(int cin, int cout, const float *w, float *dst);   // 36 * cin * cout floats, conv3x3_wino4p's xi order
 hipError_t w2xc_launch_wino4p(const W2xcConvDesc &d, hipStream_t stream);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);

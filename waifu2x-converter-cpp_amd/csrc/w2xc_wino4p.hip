@@ -51,11 +51,23 @@ __device__ unsigned long long w4_stamps[2][8192];
 #else
 #define W4_STAMP(idx) do { } while (0)
 #endif
-#ifndef W4P_PRIO
-#define W4P_PRIO 0   // experiment: s_setprio of a wave inside the stages that carry its transform work
+#ifndef W4P_NOP
+#define W4P_NOP -1   // experiment: s_nop W4P_NOP behind every MFMA (-1 = none); W4P_NOP2 = 1: a second one
+#endif
+#ifndef W4P_NOP2
+#define W4P_NOP2 0
+#endif
+#ifndef W4P_SVC
+#define W4P_SVC 0    // where a stage's non-MFMA work sits: 0 = spread over the first MFMA slots | 1 = one block in front of the first MFMA | 2 = one block,
+#endif               // in front of the first MFMA in the waves of block tile 1, behind MFMA 31 in those of block tile 0 (the two waves of a SIMD in opposite phases)
+#ifndef W4P_CLOSE_AT
+#define W4P_CLOSE_AT 32   // MFMA slot in front of which a stage's closing wait + barrier sit (a multiple of 4 >= 28; 32 = in front of the last group)
+#endif
+#ifndef W4P_T0
+#define W4P_T0 3     // MFMA slot of a stage behind which a wave's transform arithmetic starts (its LDS reads sit behind slot 0)
 #endif
 #ifndef W4_ABL
-#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores
+#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores | 128 no operand reads inside the stages
 #endif
 
 namespace {
@@ -86,6 +98,31 @@ static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// position (i, j) of the transformed domain in the fragment order: the column halves j < 3 / j >= 3 as the xi ranges [0, 18) / [18, 36)
+static constexpr __host__ __device__ int xi_of(int i, int j) { return j < 3 ? 3 * i + j : 18 + 3 * i + (j - 3); }
+// index in a quarter's 18 registers of the value at xi, -1 if the quarter does not own it.  KIND 0 / 1 (row pass of raw rows 3 h .. 3 h + 2):
+// dd[6 r + j] = row 3 h + r, column j.  KIND 2 / 3 (column pass of columns 3 h .. 3 h + 2): dd[6 jj + i] = row i of column 3 h + jj.
+static constexpr __host__ __device__ int w4p_own(int kind, int xi)
+{
+    const int h = kind & 1, half = xi / 18, rem = xi % 18, i = rem / 3, jj = rem % 3;
+    if (kind < 2) return i / 3 == h ? (i - 3 * h) * 6 + 3 * half + jj : -1;
+    return half == h ? jj * 6 + i : -1;
+}
+// the n-th quad (four consecutive xi) a quarter touches, -1 past the end: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
+static constexpr __host__ __device__ int w4p_quad(int kind, int n)
+{
+    int seen = 0;
+    for (int q = 0; q < 9; q++) {
+        bool any = false;
+        for (int e = 0; e < 4; e++) any = any || w4p_own(kind, 4 * q + e) >= 0;
+        if (any) {
+            if (seen == n) return q;
+            seen++;
+        }
+    }
+    return -1;
+}
 
 }   // namespace
 
@@ -191,64 +228,114 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int til
     const unsigned tr_rd = (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);               // + buffer + i * 144 (+ 16)
     const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);  // + slot * V_BYTES + (xi / 4) * 2048
 
-    float dd[36];
-    // (indices arrive as integral constants: register arrays indexed through a run-time lambda parameter end up in scratch)
-    auto pa_read = [&](const char *src, auto I) {               // patch row i
-        constexpr int i = decltype(I)::value;
+    // The input transform V = B^T d B of a patch in FOUR QUARTERS, one per wave and stage (KIND = the wave's plane tile pt, fixed for the kernel):
+    //   KIND 0 / 1  (for stage g + 2)  rows 0..2 / 3..5 of the raw patch: 3 x (ds_read_b128 + ds_read_b64), the row pass s[i][.] = d[i][.] B
+    //               (3 x 14 fma / add), the 18 results parked in the V slot of stage g + 2;
+    //   KIND 2 / 3  (for stage g + 1)  columns 0..2 / 3..5: the 18 parked values s[.][j] back, the column pass V[.][j] = B^T s[.][j] (3 x 14),
+    //               the 18 final values to the same addresses.
+    // Position (i, j) of the transformed domain sits at xi = xi_of(i, j) = 3 i + j (j < 3), 18 + 3 i + j - 3 (j >= 3) of the fragment order
+    // (the weight image and the epilogue use the same map): the column halves are the xi ranges [0, 18) and [18, 36), so a KIND 2 / 3 lane
+    // reads and rewrites only its own half (lane-private addresses, nothing of another wave's quarter).  Every wave carries the same 42 VALU
+    // instructions in every stage -- in round 3 and in the first version of this kernel one wave of a SIMD carried a whole (then half a) transform
+    // while its partner carried none, finished its MFMAs early, and left the transforming wave alone on the SIMD where a VALU instruction
+    // between MFMAs costs 11 cycles instead of 2 (3300-cycle stages against 2304 of MFMA time, s_memtime).
+    float dd[18];
+    // the 18 values a quarter owns, by xi: KIND 0 / 1 own rows 3 h .. 3 h + 2 (both column halves), KIND 2 / 3 own [18 h, 18 h + 18); dd index of xi:
+    // move the owned values of quad q (xi = 4 q .. 4 q + 3) between dd and LDS with the widest aligned accesses
+    auto quad_io = [&](auto KIND_, auto Q_, auto WR_, char *p) {
+        constexpr int kind = decltype(KIND_)::value, q = decltype(Q_)::value;
+        constexpr bool wr = decltype(WR_)::value;
+        constexpr int i0 = w4p_own(kind, 4 * q), i1 = w4p_own(kind, 4 * q + 1), i2 = w4p_own(kind, 4 * q + 2), i3 = w4p_own(kind, 4 * q + 3);
+        char *a = p + q * 2048;
         if constexpr ((W4_ABL & 2) != 0) {
-            static_for<0, 6>([&](auto JJ) { dd[i * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
+            if constexpr (!wr) {
+                if constexpr (i0 >= 0) dd[i0] = 1.0f;
+                if constexpr (i1 >= 0) dd[i1] = 2.0f;
+                if constexpr (i2 >= 0) dd[i2] = 3.0f;
+                if constexpr (i3 >= 0) dd[i3] = 4.0f;
+            }
+        } else if constexpr (i0 >= 0 && i1 >= 0 && i2 >= 0 && i3 >= 0) {
+            if constexpr (wr) *reinterpret_cast<f32x4 *>(a) = f32x4{dd[i0], dd[i1], dd[i2], dd[i3]};
+            else { const f32x4 v = *reinterpret_cast<const f32x4 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; dd[i2] = v[2]; dd[i3] = v[3]; }
+        } else {
+            if constexpr (i0 >= 0 && i1 >= 0) {
+                if constexpr (wr) *reinterpret_cast<f32x2 *>(a) = f32x2{dd[i0], dd[i1]};
+                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; }
+            } else {
+                if constexpr (i0 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a) = dd[i0]; else dd[i0] = *reinterpret_cast<const float *>(a); }
+                if constexpr (i1 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 4) = dd[i1]; else dd[i1] = *reinterpret_cast<const float *>(a + 4); }
+            }
+            if constexpr (i2 >= 0 && i3 >= 0) {
+                if constexpr (wr) *reinterpret_cast<f32x2 *>(a + 8) = f32x2{dd[i2], dd[i3]};
+                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a + 8); dd[i2] = v[0]; dd[i3] = v[1]; }
+            } else {
+                if constexpr (i2 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 8) = dd[i2]; else dd[i2] = *reinterpret_cast<const float *>(a + 8); }
+                if constexpr (i3 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 12) = dd[i3]; else dd[i3] = *reinterpret_cast<const float *>(a + 12); }
+            }
+        }
+    };
+    // KIND 0 / 1: raw row 3 h + r of the patch into dd[6 r .. 6 r + 5]
+    auto raw_read = [&](auto KIND_, auto R_, const char *src) {
+        constexpr int h = decltype(KIND_)::value & 1, r = decltype(R_)::value, i = 3 * h + r;
+        if constexpr ((W4_ABL & 2) != 0) {
+            static_for<0, 6>([&](auto JJ) { dd[r * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
         } else {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(src + i * 144);
             const f32x2 b = *reinterpret_cast<const f32x2 *>(src + i * 144 + 16);
-            dd[i * 6 + 0] = a[0]; dd[i * 6 + 1] = a[1]; dd[i * 6 + 2] = a[2]; dd[i * 6 + 3] = a[3];
-            dd[i * 6 + 4] = b[0]; dd[i * 6 + 5] = b[1];
+            dd[r * 6 + 0] = a[0]; dd[r * 6 + 1] = a[1]; dd[r * 6 + 2] = a[2]; dd[r * 6 + 3] = a[3];
+            dd[r * 6 + 4] = b[0]; dd[r * 6 + 5] = b[1];
         }
     };
-    auto pa_mask = [&](int xlim) {                               // patch columns outside the plane: zero (wave-uniform test first)
+    auto raw_mask = [&](int xlim) {                               // patch columns outside the plane: zero (wave-uniform test first)
         if (xlim < 34) {
             const int lim = xlim - 4 * tr_c;
-            static_for<0, 36>([&](auto E) {
+            static_for<0, 18>([&](auto E) {
                 constexpr int e = decltype(E)::value;
                 dd[e] = (e % 6) < lim ? dd[e] : 0.0f;
             });
         }
     };
-    auto tr_col = [&](auto J) {
-        constexpr int j = decltype(J)::value;
-        if constexpr (!(W4_ABL & 3)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
+    auto pass6 = [&](auto G_) {                                    // bt6 over dd[6 g .. 6 g + 5]: a raw row (KIND 0 / 1) or a column of s (KIND 2 / 3)
+        constexpr int g = decltype(G_)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5]);
     };
-    auto quad_write = [&](char *dst, auto Q4) {
-        constexpr int q4 = decltype(Q4)::value;
-        if constexpr (!(W4_ABL & 2)) *reinterpret_cast<f32x4 *>(dst + q4 * 2048) = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
-    };
-    auto quad_read = [&](const char *src, auto Q4) {
-        constexpr int q4 = decltype(Q4)::value;
-        if constexpr ((W4_ABL & 2) != 0) {
-            dd[4 * q4] = dd[4 * q4 + 1] = dd[4 * q4 + 2] = dd[4 * q4 + 3] = (float)q4;
-        } else {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + q4 * 2048);
-            dd[4 * q4] = a[0]; dd[4 * q4 + 1] = a[1]; dd[4 * q4 + 2] = a[2]; dd[4 * q4 + 3] = a[3];
-        }
-    };
-    auto tr_row = [&](char *dst, auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (!(W4_ABL & 3)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
-        // the quads of four consecutive xi that this row completes: 4 q + 3 <= 6 i + 5 and not already complete after row i - 1
-        static_for<(i == 0 ? 0 : (6 * i - 4) / 4 + 1), (6 * i + 2) / 4 + 1>([&](auto Q4) { quad_write(dst, Q4); });
+    using CT = std::true_type;
+    using CF = std::false_type;
+    // the quads a quarter touches: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
+    auto quads_io = [&](auto KIND_, auto WR_, char *p, auto FIRST_, auto LAST_) {   // quads [FIRST, LAST) of the kind's list
+        constexpr int kind = decltype(KIND_)::value, first = decltype(FIRST_)::value, last = decltype(LAST_)::value;
+        static_for<first, last>([&](auto N_) {
+            constexpr int q = w4p_quad(kind, decltype(N_)::value);
+            if constexpr (q >= 0) quad_io(KIND_, std::integral_constant<int, q>{}, WR_, p);
+        });
     };
 
-    // Wave (bt, pt) transforms for the stages g' = pt + 2 bt (mod 4): phase A in stage g' - 2, phase B in stage g' - 1.  With PH = (pt - 2 bt) mod 4
-    // its roles inside a group of four stages (global stage count mod 4 = j) are fixed at compile time -- a run-time "is it my turn" around the stage
-    // bodies joins 144 accumulators in phi nodes and the register allocator gives up -- so the item loop exists four times and a wave picks its copy once.
-    auto run = [&](auto PH_) {
-    constexpr int PH = decltype(PH_)::value;
-    // ---- prologue: raw slices 0, 1 and U(stage 0) of the first item; V(stage 0) whole, phase A of V(stage 1); raw slice 2 ----
-    tile_offsets(item_of(0));
-    int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
+    auto run = [&](auto KIND_, auto BT_) {
+    constexpr int KIND = decltype(KIND_)::value;
+    constexpr int BT = decltype(BT_)::value;   // (only W4P_SVC = 2 distinguishes the two block tiles at compile time)
+    (void)BT;
+    using CK = std::integral_constant<int, KIND>;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    using C3 = std::integral_constant<int, 3>;
+    using C6 = std::integral_constant<int, 6>;
     using U0 = std::integral_constant<unsigned, 0u>;
-    using U1 = std::integral_constant<unsigned, 1u>;
+    // a whole quarter outside the stages (prologue)
+    auto quarter = [&](const char *src, char *slot, int xlim) {
+        if constexpr (KIND < 2) {
+            static_for<0, 3>([&](auto R) { raw_read(CK{}, R, src); });
+            raw_mask(xlim);
+            static_for<0, 3>([&](auto G) { pass6(G); });
+            quads_io(CK{}, CT{}, slot, C0{}, C6{});
+        } else {
+            quads_io(CK{}, CF{}, slot, C0{}, C6{});
+            static_for<0, 3>([&](auto G) { pass6(G); });
+            quads_io(CK{}, CT{}, slot, C0{}, C6{});
+        }
+    };
+    // ---- prologue: raw slices 0..2 and U(stage 0) of the first item; V(stage 0) whole, the row pass of V(stage 1); raw slice 3 ----
+    tile_offsets(item_of(0));
+    int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
     for (int sl = 0; sl < 3; sl++) {
         dma_raw(C0{}, (unsigned)sl * RAW_BYTES, sl);
         if (wave < 3) dma_raw(C1{}, (unsigned)sl * RAW_BYTES, sl);
@@ -261,23 +348,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int til
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (PH == 0 || PH == 1) {
-        const char *src = ldsb + PH * RAW_BYTES + tr_rd;
-        char *dst = ldsb + tr_wr + PH * V_BYTES;
-        static_for<0, 6>([&](auto I) { pa_read(src, I); });
-        pa_mask(xlim_cur);
-        static_for<0, 6>([&](auto J) { tr_col(J); });
-        if constexpr (PH == 0) static_for<0, 6>([&](auto I) { tr_row(dst, I); });
-        else static_for<0, 9>([&](auto Q4) { quad_write(dst, Q4); });
-    }
+    if constexpr (KIND < 2) quarter(ldsb + tr_rd, ldsb + tr_wr, xlim_cur);                          // rows of slice 0 -> slot 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    dma_raw(C0{}, 0u, 3);   // (waited for by the first stage's closing wait: phase A of the second stage reads it)
+    dma_raw(C0{}, 0u, 3);   // (waited for by the first stage's closing wait: the row pass of the second stage reads it)
     if (wave < 3) dma_raw(C1{}, 0u, 3);
+    if constexpr (KIND < 2) quarter(ldsb + RAW_BYTES + tr_rd, ldsb + tr_wr + V_BYTES, xlim_cur);    // rows of slice 1 -> slot 1
+    else quarter(nullptr, ldsb + tr_wr, 0);                                                          // columns of slot 0: V(stage 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
+    // MFMA operand quads (four xi per ds_read_b128 and operand), read two groups of four MFMAs ahead, three register buffers each.  The closing wait and
+    // the barrier of a stage sit in front of its LAST group: behind the barrier the wave reads the first two groups of the NEXT stage and still has four
+    // MFMAs of this one to issue while they arrive -- with the barrier behind the last MFMA every stage began with an exposed LDS round trip (~400 of
+    // ~3000 cycles, s_memtime).
+    f32x4 a4[3], b4[3];
+    auto load_first = [&](unsigned u_slot, unsigned v_off) {
+        const char *ua = ldsb + ua0 + u_slot * U_BYTES;
+        const char *va = ldsb + va0 + v_off;
+        static_for<0, 2>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            a4[g] = *reinterpret_cast<const f32x4 *>(ua + g * 4096);
+            b4[g] = *reinterpret_cast<const f32x4 *>(va + g * 2048);
+        });
+    };
     unsigned v0 = 0, v1 = V_BYTES, v2 = 2 * V_BYTES;   // byte offsets of the V slots of stages g, g + 1, g + 2
-    unsigned r0 = 0, r1 = RAW_BYTES, r2 = 2 * RAW_BYTES;   // ... of the raw buffers of the slices of stages g (= g + 3), g + 1 (= g + 4: this stage's transfer), g + 2 (phase A reads it)
+    unsigned r0 = 0, r1 = RAW_BYTES, r2 = 2 * RAW_BYTES;   // ... of the raw buffers of the slices of stages g (= g + 3), g + 1 (= g + 4: this stage's transfer), g + 2 (the row pass reads it)
     int stamp = 0;
     (void)stamp;
     W4_STAMP(stamp++);
@@ -287,103 +385,125 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int til
 #pragma unroll
         for (int xi = 0; xi < 36; xi++) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // one stage; J = global stage count mod 4 (NST is a multiple of 4: = s mod 4)
+        // one stage; J = global stage count mod 2 (NST is even: = s mod 2) = its U slot
         auto stage = [&](auto J_, int s) {
             constexpr int J = decltype(J_)::value;
-            constexpr int role = J == ((PH + 2) & 3) ? 1 : J == ((PH + 3) & 3) ? 2 : 0;   // 1 = phase A (for stage g + 2), 2 = phase B (for stage g + 1)
-            constexpr unsigned par = J & 1, nxt = par ^ 1u;                               // U slot of this stage / the next; raw buffer of stage g + 2 = par
+            constexpr unsigned par = J & 1, nxt = par ^ 1u;
             int u_ob = item % NOB, u_s = s + 1;
             if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
             const char *ua = ldsb + ua0 + par * U_BYTES;
             const char *va = ldsb + va0 + v0;
             const char *srcA = ldsb + r2 + tr_rd;
-            char *dstA = ldsb + tr_wr + v2;
-            char *dstB = ldsb + tr_wr + v1;
+            char *slotA = ldsb + tr_wr + v2;
+            char *slotB = ldsb + tr_wr + v1;
             const int xlimA = s + 2 < NST ? xlim_cur : xlim_r;
             if constexpr (J == 0) {
                 if (s == NST - 4) tile_offsets(item_n);   // from this stage on the raw cursor (four stages ahead) is in the next item's tile
             }
             const int r_slice = s + 4 < NST ? s + 4 : s + 4 - NST;
             // operands of four xi per ds_read_b128; the quads of the next four xi are read while these four multiply
-            f32x4 a4[2], b4[2];
-            if constexpr (role != 0 && W4P_PRIO != 0) __builtin_amdgcn_s_setprio(W4P_PRIO);
-            a4[0] = *reinterpret_cast<const f32x4 *>(ua);
-            b4[0] = *reinterpret_cast<const f32x4 *>(va);
+            constexpr int PF = 2;
+            // this wave's quarter of the input transform
+            auto tr_reads = [&]() {
+                if constexpr (KIND < 2) static_for<0, 3>([&](auto R) { raw_read(CK{}, R, srcA); });
+                else quads_io(CK{}, CF{}, slotB, C0{}, C6{});
+            };
+            auto tr_mask = [&]() { if constexpr (KIND < 2) raw_mask(xlimA); };
+            auto tr_writes = [&](auto F_, auto L_) { quads_io(CK{}, CT{}, KIND < 2 ? slotA : slotB, F_, L_); };
+            // W4P_SVC = 1 / 2: everything of a stage that is not an MFMA or an operand read as ONE block -- transform reads, the seven transfers (while the
+            // reads fly), the 42 VALU instructions, the writes.  The two waves of a SIMD run their MFMAs one after the other (the older wave wins every
+            // arbitration: s_memtime shows 1300 cycles for its 36 MFMAs, then 1130 more for the younger one's), so an instruction between two MFMAs
+            // of a wave costs what it costs a wave alone on the SIMD (VALU 11, LDS 22-26 cycles of matrix-pipe time): as a block it costs its issue time.
+            auto service = [&]() {
+                tr_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(W4_ABL & 16)) {
+                    static_for<0, 4>([&](auto Q) { dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, Q); });
+                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
+                }
+                if constexpr (!(W4_ABL & 32)) {
+                    dma_raw(C0{}, r1, r_slice);
+                    if (wave < 3) dma_raw(C1{}, r1, r_slice);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                tr_mask();
+                static_for<0, 3>([&](auto G) { pass6(G); });
+                __builtin_amdgcn_sched_barrier(0);
+                tr_writes(C0{}, C6{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            constexpr int SVC_XI = W4P_SVC == 1 ? 0 : (W4P_SVC == 2 ? (BT == 0 ? 32 : 0) : -1);
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                if constexpr ((xi & 3) == 0 && xi + 4 < 36) {
-                    a4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + 1) * 4096);
-                    b4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + 1) * 2048);
+                if constexpr (xi == SVC_XI) service();
+                if constexpr (xi == W4P_CLOSE_AT) {
+                    // ---- the stage's close, in front of its last four MFMAs ----
+                    W4_STAMP(stamp++);
+                    // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
+                    // transfers -- may still fly
+                    if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
+                    else if (wave < 3) W2XC_WAIT_VMCNT(2);
+                    else W2XC_WAIT_VMCNT(1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    W4_STAMP(stamp++);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    { const unsigned tv = v0; v0 = v1; v1 = v2; v2 = tv; }
+                    { const unsigned tr = r0; r0 = r1; r1 = r2; r2 = tr; }
+                    if (s != NST - 1) load_first(nxt, v0);   // (an item's last stage: the epilogue comes first, the item loop reads them)
+                    W4_STAMP(stamp++);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) & 1][xi & 3], b4[(xi >> 2) & 1][xi & 3], acc[xi], 0, 0, 0);
+                if constexpr ((xi & 3) == 0 && (xi >> 2) + PF < 9 && !(W4_ABL & 128)) {
+                    a4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + PF) * 4096);
+                    b4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + PF) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) % (PF + 1)][xi & 3], b4[(xi >> 2) % (PF + 1)][xi & 3], acc[xi], 0, 0, 0);
+                if constexpr (W4P_NOP >= 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
+                if constexpr (W4P_NOP2 != 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
                 __builtin_amdgcn_sched_barrier(0);
-                // transfers, early in the stage: everything is waited for at its end
-                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
-                    dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 9 && !(W4_ABL & 16)) {
-                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 11 && !(W4_ABL & 32)) {
-                    dma_raw(C0{}, r1, r_slice);                // slice of stage g + 4 into the buffer phase A of stage g - 1 has read
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 13 && !(W4_ABL & 32)) {
-                    if (wave < 3) dma_raw(C1{}, r1, r_slice);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (role == 1) {
-                    if constexpr (xi < 2) {
-                        pa_read(srcA, std::integral_constant<int, 3 * xi>{});
-                        pa_read(srcA, std::integral_constant<int, 3 * xi + 1>{});
-                        pa_read(srcA, std::integral_constant<int, 3 * xi + 2>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi >= 4 && xi < 10) {
-                        if constexpr (xi == 4) pa_mask(xlimA);
-                        tr_col(std::integral_constant<int, xi - 4>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi >= 10 && xi < 13) {
-                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10)>{});
-                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10) + 1>{});
-                        quad_write(dstA, std::integral_constant<int, 3 * (xi - 10) + 2>{});
+                // the stage's other work (W4P_SVC = 0: spread over the first MFMA slots)
+                if constexpr (W4P_SVC == 0) {
+                    if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
+                        dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                } else if constexpr (role == 2) {
-                    if constexpr (xi < 3) {
-                        quad_read(dstB, std::integral_constant<int, 3 * xi>{});
-                        quad_read(dstB, std::integral_constant<int, 3 * xi + 1>{});
-                        quad_read(dstB, std::integral_constant<int, 3 * xi + 2>{});
+                    if constexpr (xi == 9 && !(W4_ABL & 16)) {
+                        if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi >= 4 && xi < 10) {
-                        tr_row(dstB, std::integral_constant<int, xi - 4>{});
+                    }
+                    if constexpr (xi == 11 && !(W4_ABL & 32)) {
+                        dma_raw(C0{}, r1, r_slice);                // slice of stage g + 4 into the buffer the row pass of stage g - 1 has read
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (xi == 13 && !(W4_ABL & 32)) {
+                        if (wave < 3) dma_raw(C1{}, r1, r_slice);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // this wave's quarter of the input transform
+                    if constexpr (xi == 0) {
+                        tr_reads();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi >= W4P_T0 && xi < W4P_T0 + 3) {
+                        if constexpr (xi == W4P_T0) tr_mask();
+                        pass6(std::integral_constant<int, xi - W4P_T0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi == W4P_T0 + 3) {
+                        tr_writes(C0{}, C3{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi == W4P_T0 + 4) {
+                        tr_writes(C3{}, C6{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             });
-            if constexpr (role != 0 && W4P_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-            W4_STAMP(stamp++);
-            // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
-            // transfers -- may still fly
-            if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
-            else if (wave < 3) W2XC_WAIT_VMCNT(2);
-            else W2XC_WAIT_VMCNT(1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_STAMP(stamp++);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            { const unsigned tv = v0; v0 = v1; v1 = v2; v2 = tv; }
-            { const unsigned tr = r0; r0 = r1; r1 = r2; r2 = tr; }
-            W4_STAMP(stamp++);
         };
+        load_first(0u, v0);
 #pragma unroll 1
-        for (int s = 0; s < NST; s += 4) {
+        for (int s = 0; s < NST; s += 2) {
             stage(std::integral_constant<int, 0>{}, s);
             stage(std::integral_constant<int, 1>{}, s + 1);
-            stage(std::integral_constant<int, 2>{}, s + 2);
-            stage(std::integral_constant<int, 3>{}, s + 3);
         }
         xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile three stages ago)
         {
@@ -409,8 +529,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int til
                 for (int e = 0; e < 4; e++)
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
-                        const float m0 = acc[0 * 6 + j][e], m1 = acc[1 * 6 + j][e], m2 = acc[2 * 6 + j][e], m3 = acc[3 * 6 + j][e], m4 = acc[4 * 6 + j][e],
-                                    m5 = acc[5 * 6 + j][e];
+                        const float m0 = acc[xi_of(0, j)][e], m1 = acc[xi_of(1, j)][e], m2 = acc[xi_of(2, j)][e], m3 = acc[xi_of(3, j)][e],
+                                    m4 = acc[xi_of(4, j)][e], m5 = acc[xi_of(5, j)][e];
                         const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                         if (rp == 0) {
                             tm[0][j][e] = m0 + s1 + s2;
@@ -458,12 +578,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4p(W2xcConvDesc d, int til
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
     };
-    switch ((pt - 2 * bt) & 3) {
-    case 0: run(std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}); break;
-    case 2: run(std::integral_constant<int, 2>{}); break;
-    default: run(std::integral_constant<int, 3>{}); break;
+#if W4P_SVC == 2
+    switch (wave) {
+    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+    case 4: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
+    case 5: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+    case 6: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
+    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}); break;
     }
+#else
+    switch (pt) {
+    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
+    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,7 +609,7 @@ bool w2xc_wino4p_supported(int cin, int cout)
 
 // wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = 6 i + j,
 // U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
-void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
+static void wino4_pack_impl(int cin, int cout, const float *w, float *dst, bool perm)
 {
     static const double GM[6][3] = {{64.0 / 81, 0, 0},
                                     {-128.0 / 243, -32.0 / 81, -8.0 / 27},
@@ -498,11 +631,15 @@ void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
                         for (int i = 0; i < 6; i++)
                             for (int j = 0; j < 6; j++) {
                                 const double u = tmp[i][0] * GM[j][0] + tmp[i][1] * GM[j][1] + tmp[i][2] * GM[j][2];
-                                const int xi = i * 6 + j;
+                                const int xi = perm ? (j < 3 ? 3 * i + j : 18 + 3 * i + (j - 3)) : i * 6 + j;
                                 dst[(((((size_t)ob * nst + s) * 9 + (xi >> 2)) * 4 + pt) * 64 + k * 16 + o) * 4 + (xi & 3)] = (float)u;
                             }
                     }
 }
+
+void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst) { wino4_pack_impl(cin, cout, w, dst, false); }
+// conv3x3_wino4p: position (i, j) at xi = 3 i + j (j < 3), 18 + 3 i + j - 3 (j >= 3) -- the two column halves of the transformed domain as two xi ranges
+void w2xc_wino4p_pack(int cin, int cout, const float *w, float *dst) { wino4_pack_impl(cin, cout, w, dst, true); }
 
 template <int CIN, int COUT, bool OUT_PLANAR>
 static hipError_t launch_wino4p(const W2xcConvDesc &d, hipStream_t stream)
