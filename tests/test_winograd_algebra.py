@@ -42,12 +42,18 @@ def _pack(w2xc, cin, cout, w):
     return dst
 
 
+def _xi_of(i, j):
+    """Position (i, j) of the transformed domain in the fragment order (w2xc_wino4.hip: xi_of): the column halves j < 3 / j >= 3 as two xi ranges."""
+    return 3 * i + j if j < 3 else 18 + 3 * i + (j - 3)
+
+
 def _unpack(cin, cout, img):
-    """U[xi][plane][channel] from [ob][s][xi / 4][pt][lane = 16 k + o][xi % 4] (w2xc_wino4_pack's comment)."""
+    """U[6 i + j][plane][channel] from [ob][s][xi / 4][pt][lane = 16 k + o][xi % 4], xi = xi_of(i, j) (w2xc_wino4_pack's comment)."""
     nst, nob = cin // 4, cout // 64
     a = img.reshape(nob, nst, 9, 4, 4, 16, 4)          # ob, s, xi >> 2, pt, k, o, xi & 3
     a = a.transpose(2, 6, 0, 3, 5, 1, 4)                # xi >> 2, xi & 3, ob, pt, o, s, k
-    return a.reshape(36, cout, cin)
+    a = a.reshape(36, cout, cin)
+    return a[[_xi_of(i, j) for i in range(6) for j in range(6)]]
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (128, 128)])

@@ -73,6 +73,11 @@ static __device__ __forceinline__ void lds_dma16_si(const void *sbase, unsigned 
                  : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
                  : "memory", "m0", "scc");
 }
+// 16-byte store at (scalar base + 32-bit per-lane byte offset): ONE address register however many stores share the lane offset
+static __device__ __forceinline__ void store16_s(const void *sbase, unsigned voff, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 #define W2XC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // s_waitcnt vmcnt(n) for an n that constant-folds after unrolling; the queue holds at most 63 entries
 static __device__ __forceinline__ void wait_vmcnt_n(int n)

@@ -141,6 +141,8 @@ struct FilterCache {
     static constexpr int SLOTS = 2;
     float *planar[2] = {nullptr, nullptr}, *nhwc[2] = {nullptr, nullptr};   // ping-pong: a call reads [ob ^ 1], writes [ob]
     size_t planar_floats[2] = {0, 0}, nhwc_floats[2] = {0, 0};
+    float *pad = nullptr, *pout = nullptr;   // conv3x3_wino4: the replicate-padded planar copy of the input planes / an aligned planar result
+    size_t pad_floats = 0, pout_floats = 0;
     char *pin = nullptr;            // SLOTS pinned bounce slots between the caller's pageable planes and the DMA engine
     size_t slot_bytes = 0;
     hipStream_t st = nullptr;
@@ -190,6 +192,8 @@ struct DevCtx {
         if (fc.st) hipStreamSynchronize(fc.st);
         for (float *p : fc.planar) if (p) hipFree(p);
         for (float *p : fc.nhwc) if (p) hipFree(p);
+        if (fc.pad) hipFree(fc.pad);
+        if (fc.pout) hipFree(fc.pout);
         if (fc.pin) hipHostFree(fc.pin);
         for (auto &e : fc.ev) if (e) hipEventDestroy(e);
         if (fc.st) hipStreamDestroy(fc.st);
@@ -272,6 +276,7 @@ bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o);
 int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o);
 bool uses_wino4(const w2xc_model *m, const w2xc_opts &o);
+bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o);
 
 W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 {
@@ -458,6 +463,25 @@ bool uses_wino4(const w2xc_model *m, const w2xc_opts &o)
         if (w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout) == W2XC_K_MFMA && layer_mid_variant(m, l, o) == MID_WINO4) return true;
     return false;
 }
+// conv3x3_wino4 reads PLANAR activations (one plane per channel, rows of roundup32(w) floats: 16-byte aligned pixel quads, tiles on 128-byte lines)
+// -- except with 32 input planes, where it reads the NHWC pixels (one 128-byte line each) that the 32-plane producers conv3x3_first / conv3x3_wino
+// write.  Layer l's output (l = 0 .. n-2) is planar when its consumer is a conv3x3_wino4 layer with 64 / 128 input planes, or when layer l is a
+// conv3x3_wino4 layer and its consumer is conv3x3_direct (any strides); everything else stays NHWC (conv3x3_wino4 writes either).  Producers that
+// write planar: conv3x3_wino4, conv3x3_first (3 -> 64 / 128), conv3x3_direct.
+bool is_wino4_layer(const w2xc_model *m, int l, const w2xc_opts &o)
+{
+    if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || o.kernel == W2XC_KERNEL_DIRECT) return false;
+    return l >= 0 && l < (int)m->layers.size() && w2xc_pick_kernel(m->layers[l].nin, m->layers[l].nout) == W2XC_K_MFMA && layer_mid_variant(m, l, o) == MID_WINO4;
+}
+bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o)   // layout of layer l's output = layer l + 1's input
+{
+    const int n = (int)m->layers.size();
+    if (l < 0 || l + 1 >= n) return false;
+    if (is_wino4_layer(m, l + 1, o)) return m->layers[l + 1].nin != 32;   // (32 input planes: conv3x3_wino4 reads the producer's NHWC pixels, one 128-byte line each)
+    if (!is_wino4_layer(m, l, o)) return false;
+    return layer_kind(m, l + 1, o) == W2XC_K_DIRECT;   // (conv3x3_last reads NHWC at 5.4 TB/s; its planar variant measured half of that: NHWC out there)
+}
+
 // fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
 // the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
 // w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
@@ -633,7 +657,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             const size_t hk = (size_t)rows + ((HL == 1 || k == n) ? 2 * (n - k) : 6 + 8 * (n - k)), wk = (size_t)w + 2 * (n - k);
             const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
             const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
-            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk * px_bytes);
+            const size_t wk_mem = planar_between(m, k - 1, o) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows start on 128-byte lines
+            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk_mem * px_bytes);
         }
     };
     int band = o.band_rows;
@@ -742,6 +767,12 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             } else {
                 d.out = c->ws[(k - 1) & 1];
                 d.out_rs = (long long)d.out_w * hl.nout; d.out_ps = hl.nout; d.out_cs = 1;
+                if (planar_between(m, k - 1, o)) {
+                    // planes of out_h rows of roundup32(out_w) floats: conv3x3_wino4 reads 16-byte pixel quads, and a tile's 32-pixel row segment
+                    // (tiles start at multiples of 32 pixels) is then ONE 128-byte line -- with rows of roundup4(w) floats every segment straddled two
+                    // lines, each written in two pieces by different workgroups (the 32 -> 32 layer in front: 2.0 ms instead of 0.8, measured)
+                    d.out_rs = (d.out_w + 31) & ~31; d.out_ps = 1; d.out_cs = d.out_rs * (long long)d.out_h;
+                }
                 if (T > 0 && d.out_terms >= 1 && d.out_terms <= 3) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
                 if (d.out_terms == 9) {   // G[half][tap][y][x]
                     d.out_rs = d.out_w; d.out_ps = 1;
@@ -1017,6 +1048,8 @@ int w2xc_model_trim(w2xc_model *m)
             if (c->ws[i]) { hipFree(c->ws[i]); c->ws[i] = nullptr; c->ws_floats[i] = 0; }
             if (c->fc.planar[i]) { hipFree(c->fc.planar[i]); c->fc.planar[i] = nullptr; c->fc.planar_floats[i] = 0; }
             if (c->fc.nhwc[i]) { hipFree(c->fc.nhwc[i]); c->fc.nhwc[i] = nullptr; c->fc.nhwc_floats[i] = 0; }
+            if (i == 0 && c->fc.pad) { hipFree(c->fc.pad); c->fc.pad = nullptr; c->fc.pad_floats = 0; }
+            if (i == 0 && c->fc.pout) { hipFree(c->fc.pout); c->fc.pout = nullptr; c->fc.pout_floats = 0; }
         }
         c->fc.res_valid = false;
         if (c->aux) { hipFree(c->aux); c->aux = nullptr; c->aux_floats = 0; }
@@ -1728,6 +1761,32 @@ int filter_on_device(w2xc_model *m, DevCtx *c, int layer, const float *in, long 
     d.in_h = d.out_h = h;
     d.in_w = d.out_w = w;
     d.off_y = d.off_x = -1;   // same-size conv, BORDER_REPLICATE via clamped loads (:141-142)
+    if (is_wino4_layer(m, layer, o)) {
+        // conv3x3_wino4 runs a valid conv on planar planes with 16-byte aligned pixel quads: the replicate border (:141-142) is made explicit in a
+        // padded planar copy of the input (one pass over Cin planes; the kernel then reads it with offset 0)
+        const long long prs = ((long long)w + 2 + 31) & ~31ll, pcs = prs * (h + 2);
+        int rc = grow(&fc.pad, &fc.pad_floats, (size_t)pcs * hl.nin);
+        if (rc) return rc;
+        HIP_TRY(w2xc_launch_pad_planar(in, in_rs, in_ps, in_cs, fc.pad, prs, pcs, h, w, hl.nin, 1, st));
+        d.in = fc.pad; d.in_rs = prs; d.in_ps = 1; d.in_cs = pcs;
+        d.in_h = h + 2; d.in_w = w + 2;
+        d.off_y = d.off_x = 0;
+        const long long ors = ((long long)w + 31) & ~31ll;
+        const bool planar_direct = out_ps == 1 && (out_rs & 3) == 0 && (out_cs & 3) == 0 && (((size_t)out) & 15) == 0 && out_rs >= (((long long)w + 3) & ~3ll);
+        const bool nhwc_direct = nhwc_ok(out, out_cs, out_rs, out_ps, hl.nout);
+        if (planar_direct || nhwc_direct) {
+            d.out = out; d.out_rs = out_rs; d.out_ps = out_ps; d.out_cs = out_cs;
+        } else {
+            rc = grow(&fc.pout, &fc.pout_floats, (size_t)ors * h * hl.nout);
+            if (rc) return rc;
+            d.out = fc.pout; d.out_rs = ors; d.out_ps = 1; d.out_cs = ors * h;
+        }
+        int r = launch_layer(c, m, layer, kind, d, st, of);
+        if (r) return r;
+        if (!(planar_direct || nhwc_direct)) HIP_TRY(w2xc_launch_repack(d.out, d.out_rs, 1, d.out_cs, out, out_rs, out_ps, out_cs, h, w, hl.nout, st));
+        if (res_nhwc) *res_nhwc = false;
+        return W2XC_OK;
+    }
     if (want_nhwc_in && !nhwc_ok(in, in_cs, in_rs, in_ps, hl.nin)) {
         int rc = grow(&fc.nhwc[ob ^ 1], &fc.nhwc_floats[ob ^ 1], px * hl.nin);
         if (rc) return rc;

@@ -81,14 +81,11 @@ hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
 // the same layer on v_mfma_f32_16x16x4_f32 with 128 accumulators per wave and two workgroups per CU (w2xc_wino16.hip);
 // d.wpk = the w2xc_wino16_pack image (16 * cin * cout floats, another fragment order)
 bool w2xc_wino16_supported(int cin, int cout);
-// Winograd F(4x4,3x3) (w2xc_wino4.hip): d.wpk = the w2xc_wino4_pack image (36 * cin * cout floats), d.wino_py = first output row mod 4
+// Winograd F(4x4,3x3) on PLANAR activations (w2xc_wino4.hip): in_ps = 1 / in_cs = plane stride; out planar (out_ps = 1) or NHWC (out_cs = 1, out_ps = cout);
+// d.wpk = the w2xc_wino4_pack image (36 * cin * cout floats), d.wino_py = first output row mod 4, off_x a non-negative multiple of 4
 bool w2xc_wino4_supported(int cin, int cout);
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
-// the same on PLANAR activations, transform in two phases (w2xc_wino4p.hip): in_ps = 1 / in_cs = plane stride; out planar (out_ps = 1) or NHWC (out_cs = 1)
-bool w2xc_wino4p_supported(int cin, int cout);
-void w2xc_wino4p_pack(int cin, int cout, const float *w, float *dst);   // 36 * cin * cout floats, conv3x3_wino4p's xi order
-hipError_t w2xc_launch_wino4p(const W2xcConvDesc &d, hipStream_t stream);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,
@@ -115,7 +112,7 @@ hipError_t w2xc_launch_repack(const float *src, long long s_rs, long long s_ps, 
                               float *dst, long long d_rs, long long d_ps, long long d_cs,
                               int h, int w, int c, hipStream_t stream);
 
-// replicate-padded planar copy (Model::filter's BORDER_REPLICATE made explicit for conv3x3_wino4p): dst is (h + 2 pad) x (w + 2 pad) per plane
+// replicate-padded planar copy (Model::filter's BORDER_REPLICATE made explicit for conv3x3_wino4): dst is (h + 2 pad) x (w + 2 pad) per plane
 hipError_t w2xc_launch_pad_planar(const float *src, long long s_rs, long long s_ps, long long s_cs, float *dst, long long d_rs, long long d_cs,
                                   int h, int w, int c, int pad, hipStream_t stream);
 

@@ -42,7 +42,7 @@
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-template <int CIN, int COUT, bool OUT_PLANAR = false>
+template <int CIN, int COUT>
 __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles_x, int nitems)
 {
     constexpr int ROWS = 16, HW = 34, HH = ROWS + 2, NPIX = HH * HW;   // 612 halo pixels
@@ -296,8 +296,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
             int tile_y, tile_x;
             tile_coords(pt, tile_y, tile_x);
             const int oy = tile_y * ROWS - d.wino_py + 4 * wave + 2 * tyl, ox = tile_x * 32 + 2 * tx;
-            float *obase = OUT_PLANAR ? d.out + (long long)(ob * 32 + 4 * kk) * d.out_cs + (long long)oy * d.out_rs + ox
-                                      : d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * kk;
+            float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 32 + 4 * kk;
             const int ty0 = tile_y * ROWS - d.wino_py;
             const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
 #pragma unroll
@@ -322,17 +321,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
                         y[i][1][e] = __builtin_amdgcn_fmed3f(y1, 0.1f * y1, 3.402823466e+38f);
                     }
                 }
-                if constexpr (OUT_PLANAR) {
-                    // planar out (what conv3x3_wino4p reads): a lane's two pixels of a row as one 8-byte store, 16 lanes = one 128-byte line.
-                    // (whole pairs: the row stride holds roundup4(out_w) pixels, the launcher checks)
-#pragma unroll
-                    for (int i = 0; i < 2; i++)
-                        if (interior || (oy + i >= 0 && oy + i < d.out_h && ox < d.out_w)) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                                *reinterpret_cast<f32x2v *>(obase + (long long)(8 * q4 + e) * d.out_cs + (long long)i * d.out_rs) = f32x2v{y[i][0][e], y[i][1][e]};
-                        }
-                } else if (interior) {
+                if (interior) {
 #pragma unroll
                     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -389,14 +378,14 @@ void w2xc_wino_pack(int cin, int cout, const float *w, float *dst)
                     }
 }
 
-template <int CIN, int COUT, bool OUT_PLANAR = false>
+template <int CIN, int COUT>
 static hipError_t launch_wino(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 1) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 32);
     constexpr size_t lds_bytes = 2 * (size_t)(4 * 10 * 1024) + 2 * (size_t)(32 * 1024) + 10 * 1024 + COUT * 4;   // tile + U ring + the DMA offset table + bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_wino<CIN, COUT, OUT_PLANAR>;
+    auto kern = conv3x3_wino<CIN, COUT>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -416,17 +405,8 @@ static hipError_t launch_wino(const W2xcConvDesc &d, hipStream_t stream)
 hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    if (d.in_ps != d.cin || d.in_cs != 1 || d.in_shift != 0 || (d.in_rs & 3) != 0) return hipErrorInvalidValue;
-    if (d.out_ps == 1 && d.cout == 32) {   // planar out: the 32-plane layers in front of a conv3x3_wino4p layer
-        if ((d.out_rs & 3) != 0 || (d.out_cs & 1) != 0 || (((size_t)d.out) & 7) != 0 || d.out_rs < ((d.out_w + 3) & ~3)) return hipErrorInvalidValue;
-        switch (d.cin) {
-        case 32:  return launch_wino<32, 32, true>(d, stream);
-        case 64:  return launch_wino<64, 32, true>(d, stream);
-        case 128: return launch_wino<128, 32, true>(d, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    if (d.out_ps != d.cout || d.out_cs != 1 || (d.out_rs & 3) != 0) return hipErrorInvalidValue;   // 16-byte accesses
+    if (d.in_ps != d.cin || d.in_cs != 1 || d.out_ps != d.cout || d.out_cs != 1 || d.in_shift != 0) return hipErrorInvalidValue;
+    if ((d.in_rs & 3) != 0 || (d.out_rs & 3) != 0) return hipErrorInvalidValue;   // 16-byte accesses
     switch (d.cin * 1000 + d.cout) {
     case 32032:  return launch_wino<32, 32>(d, stream);
     case 32064:  return launch_wino<32, 64>(d, stream);

@@ -1,38 +1,39 @@
 // w2xc_wino4.hip -- conv3x3_wino4: the 3x3 x Cin x Cout contraction of Model::filterWorker
-// (/root/reference/src/modelHandler.cpp:117-159) as Winograd F(4x4, 3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD.
+// (/root/reference/src/modelHandler.cpp:117-159) as Winograd F(4x4, 3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD,
+// on PLANAR activations (one H x W fp32 plane per channel -- the reference's own std::vector<cv::Mat> layout).
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 4x4 output block and 6x6 input patch: 36 positions xi of the transformed domain =
-//   36 independent GEMMs  M_xi[o][t] = sum_c U_xi[o][c] V_xi[c][t]  (o = output plane, t = block, c = input plane) -- 36 multiplies
-//   for 16 outputs, 2.25 per output against 4 of F(2x2,3x3) (conv3x3_wino16) and 9 of the direct sum.  fp32 throughout; the
-//   matrices are the Cook-Toom construction on the interpolation points 0, +-3/4, +-3/2, inf (every entry of B^T and A^T a dyadic rational, exact in fp32):
+//   36 independent GEMMs  M_xi[o][t] = sum_c U_xi[o][c] V_xi[c][t]  (o = output plane, t = block, c = input plane): 2.25 multiplies
+//   per output.  fp32 throughout; Cook-Toom on the points 0, +-3/4, +-3/2, inf (tools/winograd_points.py: every entry a dyadic rational):
 //     B^T = [81/64 0 -45/16 0 1 0; 0 -27/16 -9/4 3/4 1 0; 0 27/16 -9/4 -3/4 1 0; 0 -27/32 -9/16 3/2 1 0; 0 27/32 -9/16 -3/2 1 0; 0 81/64 0 -45/16 0 1]
 //     G   = [64/81 0 0; -128/243 -32/81 -8/27; -128/243 32/81 -8/27; 32/243 16/81 8/27; 32/243 -16/81 8/27; 0 0 1]
 //     A^T = [1 1 1 1 1 0; 0 3/4 -3/4 3/2 -3/2 0; 0 9/16 9/16 9/4 9/4 0; 0 27/64 -27/64 27/8 -27/8 1]
-//   The points matter (tools/winograd_points.py, numpy): Lavin & Gray's 0, +-1, +-2 (entries up to 5 and 8) put the 7-layer net at 9.5e-6 of the output
-//   range against the fp64 truth and use 3.0x the rtol 1e-4 + atol 1e-5 gate on the single-layer standard-normal filter cases (measured on the GPU:
-//   2.7e-5 abs at |out| <= 5.7: FAILS); 0, +-1/2, +-3/2: 3.0e-6 / 2.9x; these: 2.6e-6 / 0.8x -- same operation count (symmetric point pairs).
-//   (F(2x2): 1.1e-6, the direct fp32 sum 0.9e-6.)
 //
 //   Work item  16 rows x 32 pixels of output (4 x 8 blocks of 4x4) x 64 output planes.  8 waves: wave (bt, pt) owns block tile bt
-//              (16 blocks = block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
-//   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave (1152 cycles), BOTH operands from LDS in fragment order
-//              [xi / 4][tile][lane][xi % 4]: one ds_read_b128 per four xi and operand (A = U, lane = 16 k + o; B = V, lane = 16 k + t).
-//   V          is computed ONCE per (block, channel) and shared by the four plane-tile waves through LDS: in stage g the waves with
-//              pt == (g + 1 + 2 bt) mod 4 transform the patches of stage g + 1 (one 6x6 patch per lane: 36 ds_read_b32 from the raw tile,
-//              144 fma / add, 9 ds_write_b128), interleaved with their own MFMAs.  The item loop exists FOUR times (one copy per
-//              transformer phase, unrolled by four stages): see `run` below.
-//   LDS        raw[2] x 21 KiB: the 18 x 34 pixel halo tile of an 8-channel slice (two stages), 32 bytes per pixel slot, a row's pixels
-//              ordered by column mod 4 (9 slots each) so that the 8 block columns of a patch position are consecutive slots, the two
-//              16-byte halves of a slot swapped where bit 2 of its index is set (conflict-free patch reads);
-//              U[2] x 36 KiB + V[2] x 18 KiB + 6 KiB of per-lane transfer coordinates + bias = 155 KiB.
-//   Transfers  LDS-DMA, SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead), every second stage 21 raw pieces (the
-//              slice two slices ahead); U first, raw pieces last: the closing counted vmcnt leaves the raw pieces in flight.
-//   Epilogue   Y = A^T M A per output-row pair, bias, LeakyReLU, 16-byte NHWC stores.
-//   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4): interior blocks do not
-//              depend on the banding, blocks that straddle a band edge do at rounding level (every output of a block sees all 36 patch
-//              values; F(2x2) outputs do not) -- one of the two reasons this kernel is opt-in.
-// Measured (round 3, 2160x3840): 128->128 7.1 ms (conv3x3_wino16 8.8), frame 16.4 ms against 19.6; 0.52-0.55 of the fp32 MFMA rate on the multiplies
-// it issues -- what the rest is: DESIGN.md 3, profiles/r3_sweeps.log block 20.
+//              (block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
+//   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave, both operands from LDS in fragment order
+//              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand; A = U, lane = 16 k + o; B = V, lane = 16 k + t).
+//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS -- in TWO PHASES over two stages,
+//              so that every SIMD carries half a transform in every stage (a whole transform in one stage left the transforming wave
+//              alone on its SIMD for half of it: 4400-cycle stages where the MFMAs need 2304, round 3):
+//                phase A (stage g, for stage g + 2): 6 x (ds_read_b128 + ds_read_b64) of the raw tile, B^T d down the columns (84 VALU),
+//                         the 36 intermediate values PARKED in the V slot of stage g + 2 at the lane's own nine quads (lane-private);
+//                phase B (stage g + 1): the nine quads back, (.) B along the rows (84 VALU), the final V to the same addresses.
+//              Wave (bt, pt) transforms block tile bt for the stages g' = pt + 2 bt (mod 4): in every stage the four transforming waves
+//              (two in phase A, two in phase B) sit on four different SIMDs.  Nothing of a transform lives in registers across a stage
+//              boundary or an epilogue.  V is a ring of three slots (read g | final g + 1 | parked g + 2).
+//   LDS        raw[3] x 11 KiB: the 18 x 36 pixel halo tile of a 4-channel slice as 16-byte chunks (channel kk, row R, pixel quad q) at
+//              chunk index kk * 168 + R * 9 + q -- the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free;
+//              U[2] x 36 KiB + V[3] x 18 KiB + bias = 159.5 KiB.
+//   Transfers  LDS-DMA (global_load_lds_dwordx4), SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead) and 11 raw
+//              pieces (four stages ahead: phase A of stage g + 2 reads them, the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four consecutive pixels of one
+//              plane row: whole 128-byte lines from HBM, where the NHWC tile of round 3 pulled a 128-byte line per 32 bytes used.
+//   Epilogue   Y = A^T M A per output-row pair, bias, LeakyReLU; planar out: one 16-byte store = four pixels of a plane row, 8 lanes = one
+//              128-byte line (NHWC out, for a consumer that wants it: one store = a pixel's four planes).
+//   Edges      rows are clamped (replicate) in the transfer addresses; patch columns >= in_w are ZEROED in phase A (they only reach
+//              outputs >= out_w, and what is in memory there is not defined): results do not depend on memory contents outside the plane.
+//   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4); run_rows' four-rows-per-layer
+//              band geometry makes every region edge that is not a plane edge a block edge: bit-identical results across bandings.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
@@ -50,8 +51,23 @@ __device__ unsigned long long w4_stamps[2][8192];
 #else
 #define W4_STAMP(idx) do { } while (0)
 #endif
+#ifndef W4P_NOP
+#define W4P_NOP -1   // experiment: s_nop W4P_NOP behind every MFMA (-1 = none); W4P_NOP2 = 1: a second one
+#endif
+#ifndef W4P_NOP2
+#define W4P_NOP2 0
+#endif
+#ifndef W4P_SVC
+#define W4P_SVC 0    // where a stage's non-MFMA work sits: 0 = spread over the first MFMA slots | 1 = one block in front of the first MFMA | 2 = one block,
+#endif               // in front of the first MFMA in the waves of block tile 1, behind MFMA 31 in those of block tile 0 (the two waves of a SIMD in opposite phases)
+#ifndef W4P_CLOSE_AT
+#define W4P_CLOSE_AT 32   // MFMA slot in front of which a stage's closing wait + barrier sit (a multiple of 4 >= 28; 32 = in front of the last group)
+#endif
+#ifndef W4P_T0
+#define W4P_T0 3     // MFMA slot of a stage behind which a wave's transform arithmetic starts (its LDS reads sit behind slot 0)
+#endif
 #ifndef W4_ABL
-#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no patch reads | 4 no V writes | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores
+#define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores | 128 no operand reads inside the stages
 #endif
 
 namespace {
@@ -81,29 +97,51 @@ static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m
     y3 = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// position (i, j) of the transformed domain in the fragment order: the column halves j < 3 / j >= 3 as the xi ranges [0, 18) / [18, 36)
+static constexpr __host__ __device__ int xi_of(int i, int j) { return j < 3 ? 3 * i + j : 18 + 3 * i + (j - 3); }
+// index in a quarter's 18 registers of the value at xi, -1 if the quarter does not own it.  KIND 0 / 1 (row pass of raw rows 3 h .. 3 h + 2):
+// dd[6 r + j] = row 3 h + r, column j.  KIND 2 / 3 (column pass of columns 3 h .. 3 h + 2): dd[6 jj + i] = row i of column 3 h + jj.
+static constexpr __host__ __device__ int w4p_own(int kind, int xi)
+{
+    const int h = kind & 1, half = xi / 18, rem = xi % 18, i = rem / 3, jj = rem % 3;
+    if (kind < 2) return i / 3 == h ? (i - 3 * h) * 6 + 3 * half + jj : -1;
+    return half == h ? jj * 6 + i : -1;
+}
+// the n-th quad (four consecutive xi) a quarter touches, -1 past the end: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
+static constexpr __host__ __device__ int w4p_quad(int kind, int n)
+{
+    int seen = 0;
+    for (int q = 0; q < 9; q++) {
+        bool any = false;
+        for (int e = 0; e < 4; e++) any = any || w4p_own(kind, 4 * q + e) >= 0;
+        if (any) {
+            if (seen == n) return q;
+            seen++;
+        }
+    }
+    return -1;
+}
+
 }   // namespace
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tiles_x, int nitems)
 {
-    constexpr int ROWS = 16, HW = 34, HH = ROWS + 2;
+    constexpr int ROWS = 16;
     constexpr int NST = CIN / 4;                            // stages (4-channel slices) per item
-    constexpr int NSP = CIN / 8;                            // 8-channel raw slices per item
     constexpr int NOB = COUT / 64;                          // 64-plane blocks
-    constexpr int NW = 8;
-    constexpr int RSLOT = 36;                               // pixel slots per tile row: 4 column residues x 9
-    constexpr int RAW_SLOTS = HH * RSLOT;                   // 648
-    constexpr int RAW_PIECES = (RAW_SLOTS * 2 + 63) / 64;   // 21 pieces of 1 KiB (64 lanes x 16 bytes = 32 pixel slots)
-    constexpr int RPW = 3;                                  // pieces per wave (pieces >= 21 repeat the last one)
+    constexpr int CHS = 168;                                // chunks per channel of a raw buffer (18 rows x 9 quads = 162, + 6: stride = 8 mod 16)
+    constexpr int RAW_PIECES = 11;                          // 4 x 168 = 672 chunks = 10.5 pieces of 64 x 16 bytes
     constexpr unsigned RAW_BYTES = RAW_PIECES * 1024;
-    constexpr unsigned U_BASE = 2 * RAW_BYTES, U_BYTES = 36 * 1024;
+    constexpr unsigned U_BASE = 3 * RAW_BYTES, U_BYTES = 36 * 1024;
     constexpr unsigned V_BASE = U_BASE + 2 * U_BYTES, V_BYTES = 18 * 1024;
-    constexpr unsigned LOFS_BASE = V_BASE + 2 * V_BYTES;
-    constexpr unsigned BIAS_BASE = LOFS_BASE + RPW * 512 * 4;
-    static_assert(CIN % 16 == 0 && COUT % 64 == 0 && NST % 4 == 0, "planes");
+    constexpr unsigned BIAS_BASE = V_BASE + 3 * V_BYTES;
+    static_assert(CIN % 16 == 0 && COUT % 64 == 0 && NST % 4 == 0 && NST >= 8, "planes");
     constexpr int STRIP = 16;
     const int tiles_y = nitems / (NOB * tiles_x);
-    auto tile_coords = [&](int pt_, int &ty_, int &tx_) {     // strips of 16 tiles, row by row inside a strip (see conv3x3_wino16)
+    auto tile_coords = [&](int pt_, int &ty_, int &tx_) {     // strips of 16 tiles, row by row inside a strip (the next round of an XCD is the tile row below)
         const int per_strip = STRIP * tiles_y;
         int sidx = pt_ / per_strip;
         const int nfull = tiles_x / STRIP;
@@ -133,250 +171,366 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 
     for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
 
-    // ---- raw tile transfers: element e = piece * 64 + lane -> pixel slot e >> 1, 16-byte half e & 1 of its 8 channels ----
-    {
-        // (row, col, half) of this lane's elements, packed, parked in LDS: as loop-invariant registers they are 9 VGPRs the stages need
-        unsigned *lofs = reinterpret_cast<unsigned *>(ldsb + LOFS_BASE);
-#pragma unroll
-        for (int jj = 0; jj < RPW; jj++) {
-            int piece = jj * NW + wave;
-            piece = piece < RAW_PIECES ? piece : RAW_PIECES - 1;
-            const int e = piece * 64 + lane;
-            int slot = e >> 1;
-            slot = slot < RAW_SLOTS ? slot : RAW_SLOTS - 1;
-            const int row = slot / RSLOT, rem = slot - row * RSLOT;
-            const int res = rem / 9, idx = rem - res * 9;
-            int col = 4 * idx + res;
-            col = col < HW ? col : HW - 1;
-            // the two 16-byte halves of a pixel slot are SWAPPED where bit 2 of the slot's index in its residue group is set: the 8 block columns x 4
-            // channels of a patch position then hit 32 different banks (bank = 8 slot + 4 half + k)
-            lofs[jj * 512 + threadIdx.x] = (unsigned)(row | (col << 8) | ((((e & 1) ^ (idx >> 2)) & 1) << 16));
-        }
-    }
-    unsigned voff[RPW];
+    // ---- raw tile transfers: chunk ci = piece * 64 + lane -> (channel kk, row R, quad q); wave w sends pieces w and (w < 3) 8 + w ----
+    const long long cs4 = d.in_cs * 4, rs4 = d.in_rs * 4;     // bytes
+    unsigned voff[2];
     const char *a_base;
+    int xlim_r;                                                // in_w - x0 of the tile the raw cursor is in (patch columns >= it are outside the plane)
     auto tile_offsets = [&](int it) {
         int ty_, tx_;
         tile_coords(it / NOB, ty_, tx_);
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
-        const int yb = clampi(y0, 0, d.in_h - 1), xb = clampi(x0, 0, d.in_w - 1);
-        a_base = reinterpret_cast<const char *>(d.in) + ((long long)yb * d.in_rs + (long long)xb * CIN) * 4;
-        const int rs4 = (int)d.in_rs * 4;
-        const unsigned *lofs = reinterpret_cast<const unsigned *>(ldsb + LOFS_BASE);
+        const int yb = clampi(y0, 0, d.in_h - 1);
+        a_base = reinterpret_cast<const char *>(d.in) + (long long)yb * rs4;
+        xlim_r = d.in_w - x0;
+        if constexpr (IN_NHWC) {
+            // NHWC input (32 planes: a pixel = one 128-byte line, written by conv3x3_first / conv3x3_wino): a chunk = channels 4 s .. 4 s + 3 of ONE pixel,
+            // chunk index R * 36 + (x % 4) * 9 + x / 4 -- the pixels of a row grouped by column mod 4, so that the eight block columns of a patch
+            // position are consecutive chunks (conflict-free ds_read_b32 of a lane's channel); columns clamped (replicate) like the rows
+            xlim_r = 64;   // (nothing to mask)
 #pragma unroll
-        for (int jj = 0; jj < RPW; jj++) {
-            const unsigned pk = lofs[jj * 512 + threadIdx.x];
-            const int row = pk & 255, col = (pk >> 8) & 255, half = pk >> 16;
-            const int gy = clampi(y0 + row, 0, d.in_h - 1) - yb;
-            const int gx = clampi(x0 + col, 0, d.in_w - 1) - xb;
-            voff[jj] = (unsigned)(gy * rs4 + (gx * CIN + 4 * half) * 4);
+            for (int jj = 0; jj < 2; jj++) {
+                int ci = (jj * 8 + wave) * 64 + lane;
+                ci = ci < (ROWS + 2) * 36 ? ci : (ROWS + 2) * 36 - 1;
+                const int R = ci / 36, slot = ci - R * 36;
+                const int x = 4 * (slot % 9) + slot / 9;
+                const int gy = clampi(y0 + R, 0, d.in_h - 1) - yb;
+                const int gx = clampi(x0 + x, 0, d.in_w - 1);
+                voff[jj] = (unsigned)((long long)gy * rs4 + (long long)gx * (CIN * 4));
+            }
+            return;
+        }
+        const int xq_last = (d.in_w - 1) & ~3;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int ci = (jj * 8 + wave) * 64 + lane;
+            int kk = ci / CHS;
+            kk = kk < 4 ? kk : 3;
+            const int rem = ci - kk * CHS;
+            int R = rem / 9;
+            const int q = rem - R * 9;
+            R = R < ROWS + 2 ? R : ROWS + 1;
+            const int gy = clampi(y0 + R, 0, d.in_h - 1) - yb;
+            int gx = x0 + 4 * q;
+            gx = gx < xq_last ? gx : xq_last;
+            voff[jj] = (unsigned)((long long)kk * cs4 + (long long)gy * rs4 + (long long)gx * 4);
         }
     };
-    // raw cursor: the next 8-channel slice to fetch is slice r_lp of item_of(r_n), into raw buffer r_buf
-    int r_n = 0, r_lp = 0;
-    unsigned r_buf = 0;
-    auto dma_raw = [&](int jj) {
-        const char *sbase = a_base + r_lp * 32;
-        int piece = jj * NW + wave;
-        piece = piece < RAW_PIECES ? piece : RAW_PIECES - 1;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + r_buf * RAW_BYTES + (unsigned)piece * 1024u);
-        lds_dma16_s<0>(sbase, voff[jj], dst);
-    };
-    auto raw_advance = [&]() {
-        r_buf ^= 1u;
-        if (++r_lp == NSP) {
-            r_lp = 0;
-            r_n++;
-            tile_offsets(item_of(r_n));
-        }
+    // LDS destinations of the transfers are (wave base + immediate): as precomputed wave-uniform values the ~50 of them are hoisted out of the loops
+    // and the SGPR file overflows into VGPR lanes and scratch
+    const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    // raw piece jj * 8 + wave of 4-channel slice `slice` of the tile a_base / voff describe, into the raw buffer at byte offset roff
+    auto dma_raw = [&](auto JJ, unsigned roff, int slice) {
+        constexpr int jj = decltype(JJ)::value;
+        const char *sbase = a_base + (long long)slice * (IN_NHWC ? 16 : 4 * cs4);
+        lds_dma16_si<jj * 8192u>(sbase, voff[jj], wbase + roff);
     };
     // U of (64-plane block ob, stage s_): 36 pieces of 1 KiB (one per xi); wave w sends xi = w, w + 8, w + 16, w + 24 and (w < 4) 32 + w
     const unsigned b_voff = (unsigned)lane * 16u;
-    auto dma_u = [&](int ob, int s_, unsigned slot, int xi) {
-        const char *sbase = reinterpret_cast<const char *>(d.wpk) + ((size_t)(ob * NST + s_) * 36 + xi) * 1024;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + U_BASE + slot * U_BYTES + (unsigned)xi * 1024u);
-        lds_dma16_s<0>(sbase, b_voff, dst);
+    const char *wpk_w = reinterpret_cast<const char *>(d.wpk) + (size_t)wave * 1024;
+    auto dma_u = [&](int ob, int s_, auto SLOT, auto Q) {     // piece xi = 8 q + wave
+        constexpr unsigned slot = decltype(SLOT)::value;
+        constexpr int q = decltype(Q)::value;
+        const char *sbase = wpk_w + ((size_t)(ob * NST + s_) * 36 + q * 8) * 1024;
+        lds_dma16_si<U_BASE + slot * U_BYTES + q * 8192u>(sbase, b_voff, wbase);
     };
 
     // ---- addressing ----
     // MFMA operands: lane-linear dwords
     const unsigned ua0 = U_BASE + (unsigned)pt * 1024u + (unsigned)lane * 16u;    // + slot * U_BYTES + (xi / 4) * 4096: four xi per b128
     const unsigned va0 = V_BASE + (unsigned)bt * 1024u + (unsigned)lane * 16u;    // + slot * V_BYTES + (xi / 4) * 2048
-    // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch pixel (i, j) sits in raw slot
-    // (4 (2 bt + r) + i) * 36 + (j & 3) * 9 + c + (j >> 2)
+    // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch row i, columns 0..3 = chunk (kk, 4 (2 bt + r) + i, c),
+    // columns 4, 5 = the first half of chunk (kk, same row, c + 1)
     const int tr_r = lane >> 5, tr_k = (lane >> 3) & 3, tr_c = lane & 7;
-    const unsigned tr_rd = (unsigned)(((4 * (2 * bt + tr_r)) * RSLOT + tr_c) * 32 + tr_k * 4);          // + buffer + immediates + the swizzled half:
-    const unsigned tr_sw0 = (unsigned)(((tr_c >> 2) & 1) * 16), tr_sw1 = (unsigned)((((tr_c + 1) >> 2) & 1) * 16);   // patch columns 0..3 / 4, 5
+    const unsigned tr_rd = IN_NHWC ? (unsigned)((4 * (2 * bt + tr_r) * 36 + tr_c) * 16 + tr_k * 4)                // + buffer + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16
+                                   : (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);        // + buffer + i * 144 (+ 16)
     const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);  // + slot * V_BYTES + (xi / 4) * 2048
 
-    // the transform of one patch: reads (slots 0..11 of a stage), columns (12..17), rows + writes (18..23)
-    float dd[36];
-    // (indices arrive as integral constants: register arrays indexed through a run-time lambda parameter end up in scratch)
-    auto tr_read = [&](const char *src, const char *src1, auto Q) {   // three patch elements per call, Q = 0..11; src / src1: columns 0..3 / 4, 5
-        static_for<0, 3>([&](auto E3) {
-            constexpr int e = decltype(Q)::value * 3 + decltype(E3)::value, i = e / 6, j = e % 6;
-            if constexpr ((W4_ABL & 2) != 0) dd[e] = (float)e;
-            else {
-                // inline asm: as C++ loads these reads are merged into ds_read2_b32 pairs whose 8-bit offsets need extra address registers, which the
-                // compiler hoists and then SPILLS -- and a scratch reload waits with vmcnt(0), i.e. for every transfer in flight (2000 cycles per
-                // transforming stage, measured).  The compiler does not count these reads in lgkmcnt: tr_wait() below is their wait.
-                constexpr int off = i * (RSLOT * 32) + ((j & 3) * 9 + (j >> 2)) * 32;
-                const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)(j < 4 ? src : src1);
-                float v;
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
-                dd[e] = v;
+    // The input transform V = B^T d B of a patch in FOUR QUARTERS, one per wave and stage (KIND = the wave's plane tile pt, fixed for the kernel):
+    //   KIND 0 / 1  (for stage g + 2)  rows 0..2 / 3..5 of the raw patch: 3 x (ds_read_b128 + ds_read_b64), the row pass s[i][.] = d[i][.] B
+    //               (3 x 14 fma / add), the 18 results parked in the V slot of stage g + 2;
+    //   KIND 2 / 3  (for stage g + 1)  columns 0..2 / 3..5: the 18 parked values s[.][j] back, the column pass V[.][j] = B^T s[.][j] (3 x 14),
+    //               the 18 final values to the same addresses.
+    // Position (i, j) of the transformed domain sits at xi = xi_of(i, j) = 3 i + j (j < 3), 18 + 3 i + j - 3 (j >= 3) of the fragment order
+    // (the weight image and the epilogue use the same map): the column halves are the xi ranges [0, 18) and [18, 36), so a KIND 2 / 3 lane
+    // reads and rewrites only its own half (lane-private addresses, nothing of another wave's quarter).  Every wave carries the same 42 VALU
+    // instructions in every stage -- in round 3 and in the first version of this kernel one wave of a SIMD carried a whole (then half a) transform
+    // while its partner carried none, finished its MFMAs early, and left the transforming wave alone on the SIMD where a VALU instruction
+    // between MFMAs costs 11 cycles instead of 2 (3300-cycle stages against 2304 of MFMA time, s_memtime).
+    float dd[18];
+    // the 18 values a quarter owns, by xi: KIND 0 / 1 own rows 3 h .. 3 h + 2 (both column halves), KIND 2 / 3 own [18 h, 18 h + 18); dd index of xi:
+    // move the owned values of quad q (xi = 4 q .. 4 q + 3) between dd and LDS with the widest aligned accesses
+    auto quad_io = [&](auto KIND_, auto Q_, auto WR_, char *p) {
+        constexpr int kind = decltype(KIND_)::value, q = decltype(Q_)::value;
+        constexpr bool wr = decltype(WR_)::value;
+        constexpr int i0 = w4p_own(kind, 4 * q), i1 = w4p_own(kind, 4 * q + 1), i2 = w4p_own(kind, 4 * q + 2), i3 = w4p_own(kind, 4 * q + 3);
+        char *a = p + q * 2048;
+        if constexpr ((W4_ABL & 2) != 0) {
+            if constexpr (!wr) {
+                if constexpr (i0 >= 0) dd[i0] = 1.0f;
+                if constexpr (i1 >= 0) dd[i1] = 2.0f;
+                if constexpr (i2 >= 0) dd[i2] = 3.0f;
+                if constexpr (i3 >= 0) dd[i3] = 4.0f;
             }
-        });
+        } else if constexpr (i0 >= 0 && i1 >= 0 && i2 >= 0 && i3 >= 0) {
+            if constexpr (wr) *reinterpret_cast<f32x4 *>(a) = f32x4{dd[i0], dd[i1], dd[i2], dd[i3]};
+            else { const f32x4 v = *reinterpret_cast<const f32x4 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; dd[i2] = v[2]; dd[i3] = v[3]; }
+        } else {
+            if constexpr (i0 >= 0 && i1 >= 0) {
+                if constexpr (wr) *reinterpret_cast<f32x2 *>(a) = f32x2{dd[i0], dd[i1]};
+                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; }
+            } else {
+                if constexpr (i0 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a) = dd[i0]; else dd[i0] = *reinterpret_cast<const float *>(a); }
+                if constexpr (i1 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 4) = dd[i1]; else dd[i1] = *reinterpret_cast<const float *>(a + 4); }
+            }
+            if constexpr (i2 >= 0 && i3 >= 0) {
+                if constexpr (wr) *reinterpret_cast<f32x2 *>(a + 8) = f32x2{dd[i2], dd[i3]};
+                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a + 8); dd[i2] = v[0]; dd[i3] = v[1]; }
+            } else {
+                if constexpr (i2 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 8) = dd[i2]; else dd[i2] = *reinterpret_cast<const float *>(a + 8); }
+                if constexpr (i3 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 12) = dd[i3]; else dd[i3] = *reinterpret_cast<const float *>(a + 12); }
+            }
+        }
     };
-    auto tr_wait = [&]() {   // every patch read has returned (and the compiler sees the values as defined HERE)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]), "+v"(dd[4]), "+v"(dd[5]), "+v"(dd[6]), "+v"(dd[7]), "+v"(dd[8]), "+v"(dd[9]), "+v"(dd[10]),
-                       "+v"(dd[11]), "+v"(dd[12]), "+v"(dd[13]), "+v"(dd[14]), "+v"(dd[15]), "+v"(dd[16]), "+v"(dd[17]));
-        asm volatile(""
-                     : "+v"(dd[18]), "+v"(dd[19]), "+v"(dd[20]), "+v"(dd[21]), "+v"(dd[22]), "+v"(dd[23]), "+v"(dd[24]), "+v"(dd[25]), "+v"(dd[26]), "+v"(dd[27]),
-                       "+v"(dd[28]), "+v"(dd[29]), "+v"(dd[30]), "+v"(dd[31]), "+v"(dd[32]), "+v"(dd[33]), "+v"(dd[34]), "+v"(dd[35]));
+    // KIND 0 / 1: raw row 3 h + r of the patch into dd[6 r .. 6 r + 5]
+    auto raw_read = [&](auto KIND_, auto R_, const char *src) {
+        constexpr int h = decltype(KIND_)::value & 1, r = decltype(R_)::value, i = 3 * h + r;
+        if constexpr ((W4_ABL & 2) != 0) {
+            static_for<0, 6>([&](auto JJ) { dd[r * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
+        } else if constexpr (IN_NHWC) {
+            static_for<0, 6>([&](auto JJ) {
+                constexpr int j = decltype(JJ)::value;
+                dd[r * 6 + j] = *reinterpret_cast<const float *>(src + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16);
+            });
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + i * 144);
+            const f32x2 b = *reinterpret_cast<const f32x2 *>(src + i * 144 + 16);
+            dd[r * 6 + 0] = a[0]; dd[r * 6 + 1] = a[1]; dd[r * 6 + 2] = a[2]; dd[r * 6 + 3] = a[3];
+            dd[r * 6 + 4] = b[0]; dd[r * 6 + 5] = b[1];
+        }
     };
-    auto tr_col = [&](auto J) {
-        constexpr int j = decltype(J)::value;
-        if constexpr (!(W4_ABL & 1)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
+    auto raw_mask = [&](int xlim) {                               // patch columns outside the plane: zero (wave-uniform test first)
+        if (xlim < 34) {
+            const int lim = xlim - 4 * tr_c;
+            static_for<0, 18>([&](auto E) {
+                constexpr int e = decltype(E)::value;
+                dd[e] = (e % 6) < lim ? dd[e] : 0.0f;
+            });
+        }
     };
-    auto tr_row = [&](char *dst, auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (!(W4_ABL & 1)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
-        // the quads of four consecutive xi that this row completes: 4 q + 3 <= 6 i + 5 and not already complete after row i - 1
-        static_for<(i == 0 ? 0 : (6 * i - 4) / 4 + 1), (6 * i + 2) / 4 + 1>([&](auto Q4) {
-            constexpr int q4 = decltype(Q4)::value;
-            if constexpr (!(W4_ABL & 4))
-                *reinterpret_cast<f32x4 *>(dst + q4 * 2048) = f32x4{dd[4 * q4], dd[4 * q4 + 1], dd[4 * q4 + 2], dd[4 * q4 + 3]};
+    auto pass6 = [&](auto G_) {                                    // bt6 over dd[6 g .. 6 g + 5]: a raw row (KIND 0 / 1) or a column of s (KIND 2 / 3)
+        constexpr int g = decltype(G_)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5]);
+    };
+    using CT = std::true_type;
+    using CF = std::false_type;
+    // the quads a quarter touches: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
+    auto quads_io = [&](auto KIND_, auto WR_, char *p, auto FIRST_, auto LAST_) {   // quads [FIRST, LAST) of the kind's list
+        constexpr int kind = decltype(KIND_)::value, first = decltype(FIRST_)::value, last = decltype(LAST_)::value;
+        static_for<first, last>([&](auto N_) {
+            constexpr int q = w4p_quad(kind, decltype(N_)::value);
+            if constexpr (q >= 0) quad_io(KIND_, std::integral_constant<int, q>{}, WR_, p);
         });
     };
 
-    // The wave that transforms the patches of stage g + 1 (in stage g) is the one with pt == (g + 1 + 2 bt) mod 4, i.e. every wave in every
-    // fourth stage, at its own phase PH = (pt - 1 - 2 bt) mod 4.  A run-time "is it my turn" around the two stage bodies joins 144 accumulators
-    // in phi nodes after every stage and the register allocator gives up (150 spilled registers); so the whole item loop exists four times,
-    // unrolled by four stages with the transforming stage fixed at compile time, and a wave picks its copy once.
-    auto run = [&](auto PH_) {
-    constexpr int PH = decltype(PH_)::value;
-    // ---- prologue: raw slices 0 and 1 of the first item, U(stage 0), then V(stage 0) ----
+    auto run = [&](auto KIND_, auto BT_) {
+    constexpr int KIND = decltype(KIND_)::value;
+    constexpr int BT = decltype(BT_)::value;   // (only W4P_SVC = 2 distinguishes the two block tiles at compile time)
+    (void)BT;
+    using CK = std::integral_constant<int, KIND>;
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C3 = std::integral_constant<int, 3>;
+    using C6 = std::integral_constant<int, 6>;
+    using U0 = std::integral_constant<unsigned, 0u>;
+    // a whole quarter outside the stages (prologue)
+    auto quarter = [&](const char *src, char *slot, int xlim) {
+        if constexpr (KIND < 2) {
+            static_for<0, 3>([&](auto R) { raw_read(CK{}, R, src); });
+            raw_mask(xlim);
+            static_for<0, 3>([&](auto G) { pass6(G); });
+            quads_io(CK{}, CT{}, slot, C0{}, C6{});
+        } else {
+            quads_io(CK{}, CF{}, slot, C0{}, C6{});
+            static_for<0, 3>([&](auto G) { pass6(G); });
+            quads_io(CK{}, CT{}, slot, C0{}, C6{});
+        }
+    };
+    // ---- prologue: raw slices 0..2 and U(stage 0) of the first item; V(stage 0) whole, the row pass of V(stage 1); raw slice 3 ----
     tile_offsets(item_of(0));
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int jj = 0; jj < RPW; jj++) dma_raw(jj);
-        raw_advance();
+    int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
+    for (int sl = 0; sl < 3; sl++) {
+        dma_raw(C0{}, (unsigned)sl * RAW_BYTES, sl);
+        if (wave < 3) dma_raw(C1{}, (unsigned)sl * RAW_BYTES, sl);
     }
     {
         const int ob0 = item_of(0) % NOB;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dma_u(ob0, 0, 0, q * 8 + wave);
-        if (wave < 4) dma_u(ob0, 0, 0, 32 + wave);
+        static_for<0, 4>([&](auto Q) { dma_u(ob0, 0, U0{}, Q); });
+        if (wave < 4) dma_u(ob0, 0, U0{}, std::integral_constant<int, 4>{});
     }
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (PH == 3) {   // V of the first stage (stage -1 = 3 mod 4)
-        const char *src = ldsb + tr_rd + tr_sw0, *src1 = ldsb + tr_rd + tr_sw1;
-        char *dst = ldsb + tr_wr;
-        static_for<0, 12>([&](auto Q) { tr_read(src, src1, Q); });
-        tr_wait();
-        static_for<0, 6>([&](auto J) { tr_col(J); });
-        static_for<0, 6>([&](auto I) { tr_row(dst, I); });
-    }
+    if constexpr (KIND < 2) quarter(ldsb + tr_rd, ldsb + tr_wr, xlim_cur);                          // rows of slice 0 -> slot 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_raw(C0{}, 0u, 3);   // (waited for by the first stage's closing wait: the row pass of the second stage reads it)
+    if (wave < 3) dma_raw(C1{}, 0u, 3);
+    if constexpr (KIND < 2) quarter(ldsb + RAW_BYTES + tr_rd, ldsb + tr_wr + V_BYTES, xlim_cur);    // rows of slice 1 -> slot 1
+    else quarter(nullptr, ldsb + tr_wr, 0);                                                          // columns of slot 0: V(stage 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    unsigned par = 0;         // parity of the global stage count: U / V buffer of the CURRENT stage
+    // MFMA operand quads (four xi per ds_read_b128 and operand), read two groups of four MFMAs ahead, three register buffers each.  The closing wait and
+    // the barrier of a stage sit in front of its LAST group: behind the barrier the wave reads the first two groups of the NEXT stage and still has four
+    // MFMAs of this one to issue while they arrive -- with the barrier behind the last MFMA every stage began with an exposed LDS round trip (~400 of
+    // ~3000 cycles, s_memtime).
+    f32x4 a4[3], b4[3];
+    auto load_first = [&](unsigned u_slot, unsigned v_off) {
+        const char *ua = ldsb + ua0 + u_slot * U_BYTES;
+        const char *va = ldsb + va0 + v_off;
+        static_for<0, 2>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            a4[g] = *reinterpret_cast<const f32x4 *>(ua + g * 4096);
+            b4[g] = *reinterpret_cast<const f32x4 *>(va + g * 2048);
+        });
+    };
+    unsigned v0 = 0, v1 = V_BYTES, v2 = 2 * V_BYTES;   // byte offsets of the V slots of stages g, g + 1, g + 2
+    unsigned r0 = 0, r1 = RAW_BYTES, r2 = 2 * RAW_BYTES;   // ... of the raw buffers of the slices of stages g (= g + 3), g + 1 (= g + 4: this stage's transfer), g + 2 (the row pass reads it)
     int stamp = 0;
     (void)stamp;
     W4_STAMP(stamp++);
-    unsigned r_buf_cur = 0;   // raw buffer of the current stage's 8-channel slice
     for (int n = 0; n < nmy; n++) {
         const int item = item_of(n), item_n = item_of(n + 1);
         f32x4 acc[36];
 #pragma unroll
         for (int xi = 0; xi < 36; xi++) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // one stage; ODD = stage parity (odd stages carry the raw transfers), TR = this wave transforms the next stage's patches
-        auto stage = [&](auto ODD_, auto TR_, int s) {
-            constexpr bool odd = decltype(ODD_)::value;
-            constexpr bool tr = decltype(TR_)::value;
+        // one stage; J = global stage count mod 2 (NST is even: = s mod 2) = its U slot
+        auto stage = [&](auto J_, int s) {
+            constexpr int J = decltype(J_)::value;
+            constexpr unsigned par = J & 1, nxt = par ^ 1u;
             int u_ob = item % NOB, u_s = s + 1;
             if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
-            const unsigned nxt = par ^ 1u;
             const char *ua = ldsb + ua0 + par * U_BYTES;
-            const char *va = ldsb + va0 + par * V_BYTES;
-            // next stage's patches: raw slice of global stage g + 1; stage parity odd -> g + 1 even -> first half of the NEXT raw buffer
-            const unsigned rb = odd ? (r_buf_cur ^ 1u) : r_buf_cur;
-            const char *src = ldsb + rb * RAW_BYTES + tr_rd + ((odd ? 0u : 16u) ^ tr_sw0);
-            const char *src1 = ldsb + rb * RAW_BYTES + tr_rd + ((odd ? 0u : 16u) ^ tr_sw1);
-            char *dst = ldsb + tr_wr + nxt * V_BYTES;
+            const char *va = ldsb + va0 + v0;
+            const char *srcA = ldsb + r2 + tr_rd;
+            char *slotA = ldsb + tr_wr + v2;
+            char *slotB = ldsb + tr_wr + v1;
+            const int xlimA = s + 2 < NST ? xlim_cur : xlim_r;
+            if constexpr (J == 0) {
+                if (s == NST - 4) tile_offsets(item_n);   // from this stage on the raw cursor (four stages ahead) is in the next item's tile
+            }
+            const int r_slice = s + 4 < NST ? s + 4 : s + 4 - NST;
             // operands of four xi per ds_read_b128; the quads of the next four xi are read while these four multiply
-            f32x4 a4[2], b4[2];
-            a4[0] = *reinterpret_cast<const f32x4 *>(ua);
-            b4[0] = *reinterpret_cast<const f32x4 *>(va);
+            constexpr int PF = 2;
+            // this wave's quarter of the input transform
+            auto tr_reads = [&]() {
+                if constexpr (KIND < 2) static_for<0, 3>([&](auto R) { raw_read(CK{}, R, srcA); });
+                else quads_io(CK{}, CF{}, slotB, C0{}, C6{});
+            };
+            auto tr_mask = [&]() { if constexpr (KIND < 2) raw_mask(xlimA); };
+            auto tr_writes = [&](auto F_, auto L_) { quads_io(CK{}, CT{}, KIND < 2 ? slotA : slotB, F_, L_); };
+            // W4P_SVC = 1 / 2: everything of a stage that is not an MFMA or an operand read as ONE block -- transform reads, the seven transfers (while the
+            // reads fly), the 42 VALU instructions, the writes.  The two waves of a SIMD run their MFMAs one after the other (the older wave wins every
+            // arbitration: s_memtime shows 1300 cycles for its 36 MFMAs, then 1130 more for the younger one's), so an instruction between two MFMAs
+            // of a wave costs what it costs a wave alone on the SIMD (VALU 11, LDS 22-26 cycles of matrix-pipe time): as a block it costs its issue time.
+            auto service = [&]() {
+                tr_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(W4_ABL & 16)) {
+                    static_for<0, 4>([&](auto Q) { dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, Q); });
+                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
+                }
+                if constexpr (!(W4_ABL & 32)) {
+                    dma_raw(C0{}, r1, r_slice);
+                    if (wave < 3) dma_raw(C1{}, r1, r_slice);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                tr_mask();
+                static_for<0, 3>([&](auto G) { pass6(G); });
+                __builtin_amdgcn_sched_barrier(0);
+                tr_writes(C0{}, C6{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            constexpr int SVC_XI = W4P_SVC == 1 ? 0 : (W4P_SVC == 2 ? (BT == 0 ? 32 : 0) : -1);
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                if constexpr ((xi & 3) == 0 && xi + 4 < 36) {
-                    a4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + 1) * 4096);
-                    b4[((xi >> 2) + 1) & 1] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + 1) * 2048);
+                if constexpr (xi == SVC_XI) service();
+                if constexpr (xi == W4P_CLOSE_AT) {
+                    // ---- the stage's close, in front of its last four MFMAs ----
+                    W4_STAMP(stamp++);
+                    // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
+                    // transfers -- may still fly
+                    if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
+                    else if (wave < 3) W2XC_WAIT_VMCNT(2);
+                    else W2XC_WAIT_VMCNT(1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    W4_STAMP(stamp++);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    { const unsigned tv = v0; v0 = v1; v1 = v2; v2 = tv; }
+                    { const unsigned tr = r0; r0 = r1; r1 = r2; r2 = tr; }
+                    if (s != NST - 1) load_first(nxt, v0);   // (an item's last stage: the epilogue comes first, the item loop reads them)
+                    W4_STAMP(stamp++);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) & 1][xi & 3], b4[(xi >> 2) & 1][xi & 3], acc[xi], 0, 0, 0);
+                if constexpr ((xi & 3) == 0 && (xi >> 2) + PF < 9 && !(W4_ABL & 128)) {
+                    a4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + PF) * 4096);
+                    b4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + PF) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) % (PF + 1)][xi & 3], b4[(xi >> 2) % (PF + 1)][xi & 3], acc[xi], 0, 0, 0);
+                if constexpr (W4P_NOP >= 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
+                if constexpr (W4P_NOP2 != 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
                 __builtin_amdgcn_sched_barrier(0);
-                // transfers: U pieces first, raw pieces last
-                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
-                    dma_u(u_ob, u_s, nxt, ((xi - 1) >> 1) * 8 + wave);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 9 && !(W4_ABL & 16)) {
-                    if (wave < 4) dma_u(u_ob, u_s, nxt, 32 + wave);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (odd && (xi == 29 || xi == 31 || xi == 33) && !(W4_ABL & 32)) {
-                    dma_raw((xi - 29) >> 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (tr) {
-                    // the whole transform in the first half of the stage, while the partner wave of the SIMD still issues MFMAs: s_memtime per slot
-                    // showed the row pass at slots 18..23 -- after the partner had finished -- costing 1950 cycles, the identical column pass at 12..17 360
-                    if constexpr (xi < 6) {
-                        tr_read(src, src1, std::integral_constant<int, 2 * xi>{});
-                        tr_read(src, src1, std::integral_constant<int, 2 * xi + 1>{});
+                // the stage's other work (W4P_SVC = 0: spread over the first MFMA slots)
+                if constexpr (W4P_SVC == 0) {
+                    if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
+                        dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi < 12) {
-                        if constexpr (xi == 6) tr_wait();
-                        tr_col(std::integral_constant<int, xi - 6>{});
+                    }
+                    if constexpr (xi == 9 && !(W4_ABL & 16)) {
+                        if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi < 18) {
-                        tr_row(dst, std::integral_constant<int, xi - 12>{});
+                    }
+                    if constexpr (xi == 11 && !(W4_ABL & 32)) {
+                        dma_raw(C0{}, r1, r_slice);                // slice of stage g + 4 into the buffer the row pass of stage g - 1 has read
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (xi == 13 && !(W4_ABL & 32)) {
+                        if (wave < 3) dma_raw(C1{}, r1, r_slice);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // this wave's quarter of the input transform
+                    if constexpr (xi == 0) {
+                        tr_reads();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi >= W4P_T0 && xi < W4P_T0 + 3) {
+                        if constexpr (xi == W4P_T0) tr_mask();
+                        pass6(std::integral_constant<int, xi - W4P_T0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi == W4P_T0 + 3) {
+                        tr_writes(C0{}, C3{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (xi == W4P_T0 + 4) {
+                        tr_writes(C3{}, C6{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             });
-            if constexpr (odd) {
-                raw_advance();
-                r_buf_cur ^= 1u;
-            }
-            W4_STAMP(stamp++);
-            if constexpr (odd && !(W4_ABL & 32)) W2XC_WAIT_VMCNT(RPW);     // U(next stage) has landed; this stage's raw pieces (the youngest) may still fly
-            else W2XC_WAIT_VMCNT(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_STAMP(stamp++);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            par = nxt;
-            W4_STAMP(stamp++);
         };
+        load_first(0u, v0);
 #pragma unroll 1
-        for (int s = 0; s < NST; s += 4) {   // (NST is a multiple of 4: the global stage count mod 4 = s mod 4)
-            stage(std::false_type{}, std::integral_constant<bool, PH == 0>{}, s);
-            stage(std::true_type{}, std::integral_constant<bool, PH == 1>{}, s + 1);
-            stage(std::false_type{}, std::integral_constant<bool, PH == 2>{}, s + 2);
-            stage(std::true_type{}, std::integral_constant<bool, PH == 3>{}, s + 3);
+        for (int s = 0; s < NST; s += 2) {
+            stage(std::integral_constant<int, 0>{}, s);
+            stage(std::integral_constant<int, 1>{}, s + 1);
         }
+        xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile three stages ago)
         {
-            // ---- epilogue: Y = A^T M A, bias, LeakyReLU, NHWC stores.  C/D of the 16x16 MFMA: lane & 15 = block, register e = plane
+            // ---- epilogue: Y = A^T M A, bias, LeakyReLU, stores.  C/D of the 16x16 MFMA: lane & 15 = block, register e = plane
             //      4 (lane >> 4) + e of the plane tile ----
             __builtin_amdgcn_s_setprio(2);
             const int ob = item % NOB;
@@ -384,13 +538,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             tile_coords(item / NOB, tile_y, tile_x);
             const int ty0 = tile_y * ROWS - d.wino_py;
             const int oy = ty0 + 4 * (2 * bt + (t >> 3)), ox = tile_x * 32 + 4 * (t & 7);
-            float *obase = d.out + (long long)oy * d.out_rs + (long long)ox * COUT + ob * 64 + pt * 16 + 4 * k;
+            const int plane0 = ob * 64 + pt * 16 + 4 * k;
+            float *obase = OUT_PLANAR ? d.out + (long long)plane0 * d.out_cs + (long long)oy * d.out_rs + ox
+                                      : d.out + (long long)oy * d.out_rs + (long long)ox * COUT + plane0;
             const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + (ob * 64 + pt * 16 + 4 * k) * 4);
-            // Two output ROWS of the block at a time, all four planes of a lane: 16-byte stores (a lane's four planes of a pixel; the four lanes
-            // of a block cover 64 contiguous bytes) -- 16 store instructions per lane instead of the 32 eight-byte ones of the first version,
-            // whose 8 x 32 scattered stores per item kept the CU's address unit busy for 16000 cycles.  The row transform of a column is done
-            // per row PAIR (7 operations instead of 10 for all four rows): 48 + 32 live values beside the 144 accumulators.
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + plane0 * 4);
+            // Two output ROWS of the block at a time (the row transform of a column per row PAIR: 7 operations instead of 10 for all four rows):
+            // 48 + 16 live values beside the 144 accumulators.
 #pragma unroll
             for (int rp = 0; rp < 2; rp++) {
                 float tm[2][6][4];   // [row of the pair][column j][plane e]
@@ -398,8 +552,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 for (int e = 0; e < 4; e++)
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
-                        const float m0 = acc[0 * 6 + j][e], m1 = acc[1 * 6 + j][e], m2 = acc[2 * 6 + j][e], m3 = acc[3 * 6 + j][e], m4 = acc[4 * 6 + j][e],
-                                    m5 = acc[5 * 6 + j][e];
+                        const float m0 = acc[xi_of(0, j)][e], m1 = acc[xi_of(1, j)][e], m2 = acc[xi_of(2, j)][e], m3 = acc[xi_of(3, j)][e],
+                                    m4 = acc[xi_of(4, j)][e], m5 = acc[xi_of(5, j)][e];
                         const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                         if (rp == 0) {
                             tm[0][j][e] = m0 + s1 + s2;
@@ -412,19 +566,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
                     const int i = 2 * rp + rr;
-                    f32x4 y[4];
+                    f32x4 y[4];      // OUT_PLANAR: y[e] = the four pixels of row i of plane e; NHWC: y[j] = the four planes of pixel j
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float y0, y1, y2, y3;
                         at6(tm[rr][0][e], tm[rr][1][e], tm[rr][2][e], tm[rr][3][e], tm[rr][4][e], tm[rr][5][e], y0, y1, y2, y3);
-                        const float v0 = y0 + bq[e], v1 = y1 + bq[e], v2 = y2 + bq[e], v3 = y3 + bq[e];
-                        y[0][e] = __builtin_amdgcn_fmed3f(v0, 0.1f * v0, 3.402823466e+38f);
-                        y[1][e] = __builtin_amdgcn_fmed3f(v1, 0.1f * v1, 3.402823466e+38f);
-                        y[2][e] = __builtin_amdgcn_fmed3f(v2, 0.1f * v2, 3.402823466e+38f);
-                        y[3][e] = __builtin_amdgcn_fmed3f(v3, 0.1f * v3, 3.402823466e+38f);
+                        const float w0 = y0 + bq[e], w1 = y1 + bq[e], w2 = y2 + bq[e], w3 = y3 + bq[e];
+                        const float l0 = __builtin_amdgcn_fmed3f(w0, 0.1f * w0, 3.402823466e+38f), l1 = __builtin_amdgcn_fmed3f(w1, 0.1f * w1, 3.402823466e+38f);
+                        const float l2 = __builtin_amdgcn_fmed3f(w2, 0.1f * w2, 3.402823466e+38f), l3 = __builtin_amdgcn_fmed3f(w3, 0.1f * w3, 3.402823466e+38f);
+                        if constexpr (OUT_PLANAR) y[e] = f32x4{l0, l1, l2, l3};
+                        else { y[0][e] = l0; y[1][e] = l1; y[2][e] = l2; y[3][e] = l3; }
                     }
                     if constexpr ((W4_ABL & 64) != 0) {
                         if (y[0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0] + y[1] + y[2] + y[3];
+                    } else if constexpr (OUT_PLANAR) {
+                        // whole quads: the row stride holds roundup4(out_w) pixels (the launcher checks), columns >= out_w are never read as data
+                        if (interior || (oy + i >= 0 && oy + i < d.out_h && ox < d.out_w)) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) *reinterpret_cast<f32x4 *>(obase + (long long)e * d.out_cs + (long long)i * d.out_rs) = y[e];
+                        }
                     } else if (interior) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4 *>(obase + (long long)i * d.out_rs + j * COUT) = y[j];
@@ -441,30 +601,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
     };
-    switch ((pt - 1 - 2 * bt) & 3) {
-    case 0: run(std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}); break;
-    case 2: run(std::integral_constant<int, 2>{}); break;
-    default: run(std::integral_constant<int, 3>{}); break;
+#if W4P_SVC == 2
+    switch (wave) {
+    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+    case 4: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
+    case 5: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+    case 6: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
+    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}); break;
     }
+#else
+    switch (pt) {
+    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
+    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side
+// host side.  Two objects (make -j): W2XC_WINO4_PART = 0 the planar-out instantiations + packer + dispatcher, 1 the NHWC-out ones.
 // ------------------------------------------------------------------------------------------------
-bool w2xc_wino4_supported(int cin, int cout)
-{
-    return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
-}
-
-template <int CIN, int COUT>
+#ifndef W2XC_WINO4_PART
+#define W2XC_WINO4_PART -1   // one translation unit with everything (tools/ubench)
+#endif
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false>
 static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 3) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 64);
-    constexpr size_t lds_bytes = 2 * (size_t)(21 * 1024) + 2 * (size_t)(36 * 1024) + 2 * (size_t)(18 * 1024) + 3 * 512 * 4 + COUT * 4;   // raw + U + V + offset table + bias
+    constexpr size_t lds_bytes = 3 * (size_t)(11 * 1024) + 2 * (size_t)(36 * 1024) + 3 * (size_t)(18 * 1024) + COUT * 4;   // raw + U + V + bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_wino4<CIN, COUT>;
+    auto kern = conv3x3_wino4<CIN, COUT, OUT_PLANAR, IN_NHWC>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -480,20 +651,99 @@ static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// d.wpk = w2xc_wino4_pack image; NHWC fp32 in / out like W2XC_K_MFMA; d.wino_py = first output row mod 4
+
+hipError_t w2xc_launch_wino4_nhwc_out(const W2xcConvDesc &d, hipStream_t stream);
+#if W2XC_WINO4_PART != 0
+hipError_t w2xc_launch_wino4_nhwc_out(const W2xcConvDesc &d, hipStream_t stream)
+{
+#ifdef W4P_SINGLE
+    return hipErrorInvalidValue;
+#else
+    if (d.cin == 32 && d.in_ps == 32 && d.in_cs == 1)
+        return d.cout == 64 ? launch_wino4<32, 64, false, true>(d, stream) : d.cout == 128 ? launch_wino4<32, 128, false, true>(d, stream) : hipErrorInvalidValue;
+    switch (d.cin * 1000 + d.cout) {
+    case 32064:  return launch_wino4<32, 64, false>(d, stream);
+    case 32128:  return launch_wino4<32, 128, false>(d, stream);
+    case 64064:  return launch_wino4<64, 64, false>(d, stream);
+    case 64128:  return launch_wino4<64, 128, false>(d, stream);
+    case 128064: return launch_wino4<128, 64, false>(d, stream);
+    case 128128: return launch_wino4<128, 128, false>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+#endif
+}
+#endif
+
+#if W2XC_WINO4_PART != 1
+bool w2xc_wino4_supported(int cin, int cout)
+{
+    return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+}
+
+// wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = xi_of(i, j),
+// U = G g G^T formed in double and rounded once.  w is [cout][cin][3][3] (modelHandler.cpp:102).  36 * cin * cout floats.
+void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst)
+{
+    static const double GM[6][3] = {{64.0 / 81, 0, 0},
+                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27},
+                                    {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},
+                                    {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                    {0, 0, 1}};
+    const int nst = cin / 4, nob = cout / 64;
+    for (int ob = 0; ob < nob; ob++)
+        for (int s = 0; s < nst; s++)
+            for (int pt = 0; pt < 4; pt++)
+                for (int k = 0; k < 4; k++)
+                    for (int o = 0; o < 16; o++) {
+                        const int plane = 64 * ob + 16 * pt + o, c = 4 * s + k;
+                        const float *g = w + ((size_t)plane * cin + c) * 9;
+                        double tmp[6][3];
+                        for (int i = 0; i < 6; i++)
+                            for (int j = 0; j < 3; j++) tmp[i][j] = GM[i][0] * g[0 * 3 + j] + GM[i][1] * g[1 * 3 + j] + GM[i][2] * g[2 * 3 + j];
+                        for (int i = 0; i < 6; i++)
+                            for (int j = 0; j < 6; j++) {
+                                const double u = tmp[i][0] * GM[j][0] + tmp[i][1] * GM[j][1] + tmp[i][2] * GM[j][2];
+                                const int xi = xi_of(i, j);
+                                dst[(((((size_t)ob * nst + s) * 9 + (xi >> 2)) * 4 + pt) * 64 + k * 16 + o) * 4 + (xi & 3)] = (float)u;
+                            }
+                    }
+}
+
+
+// d.wpk = w2xc_wino4_pack image; planar fp32 in (in_ps = 1, in_cs = plane stride), planar (out_ps = 1) or NHWC (out_cs = 1, out_ps = cout) out;
+// d.wino_py = first output row mod 4; off_x a multiple of 4 (the engine's layers: 0)
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
-    if (d.in_ps != d.cin || d.in_cs != 1 || d.in_shift != 0) return hipErrorInvalidValue;
-    if (d.out_ps != d.cout || d.out_cs != 1) return hipErrorInvalidValue;
-    if ((d.in_rs & 3) != 0 || (d.out_rs & 3) != 0) return hipErrorInvalidValue;   // 16-byte accesses
+    const bool in_nhwc = d.cin == 32 && d.in_ps == 32 && d.in_cs == 1;   // the 32-plane layers in front write NHWC
+    if (d.in_shift != 0 || (d.in_rs & 3) != 0 || (((size_t)d.in) & 15) != 0) return hipErrorInvalidValue;
+    if (in_nhwc) {
+        if (24 * d.in_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;
+    } else {
+        if (d.in_ps != 1 || (d.in_cs & 3) != 0 || d.off_x < 0 || (d.off_x & 3) != 0 || d.in_rs < ((d.in_w + 3) & ~3)) return hipErrorInvalidValue;
+        if (3 * d.in_cs * 4 + 24 * d.in_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit lane offsets inside a 4-channel slice of a tile
+    }
+    const bool planar = d.out_ps == 1;
+    if (planar) {
+        if ((d.out_rs & 3) != 0 || (d.out_cs & 3) != 0 || (((size_t)d.out) & 15) != 0 || d.out_rs < ((d.out_w + 3) & ~3)) return hipErrorInvalidValue;
+    } else if (d.out_ps != d.cout || d.out_cs != 1 || (d.out_rs & 3) != 0 || (((size_t)d.out) & 15) != 0) return hipErrorInvalidValue;
+    if (!planar) return w2xc_launch_wino4_nhwc_out(d, stream);
+#ifndef W4P_SINGLE
+    if (in_nhwc) return d.cout == 64 ? launch_wino4<32, 64, true, true>(d, stream) : d.cout == 128 ? launch_wino4<32, 128, true, true>(d, stream) : hipErrorInvalidValue;
+#endif
+#ifdef W4P_SINGLE   // (development builds: one instantiation)
+    return d.cin == 128 && d.cout == 128 ? launch_wino4<128, 128, true>(d, stream) : hipErrorInvalidValue;
+#else
     switch (d.cin * 1000 + d.cout) {
-    case 32064:  return launch_wino4<32, 64>(d, stream);
-    case 32128:  return launch_wino4<32, 128>(d, stream);
-    case 64064:  return launch_wino4<64, 64>(d, stream);
-    case 64128:  return launch_wino4<64, 128>(d, stream);
-    case 128064: return launch_wino4<128, 64>(d, stream);
-    case 128128: return launch_wino4<128, 128>(d, stream);
+    case 32064:  return launch_wino4<32, 64, true>(d, stream);
+    case 32128:  return launch_wino4<32, 128, true>(d, stream);
+    case 64064:  return launch_wino4<64, 64, true>(d, stream);
+    case 64128:  return launch_wino4<64, 128, true>(d, stream);
+    case 128064: return launch_wino4<128, 64, true>(d, stream);
+    case 128128: return launch_wino4<128, 128, true>(d, stream);
     default: return hipErrorInvalidValue;
     }
+#endif
 }
+#endif
