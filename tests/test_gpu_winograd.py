@@ -122,7 +122,7 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
     assert worst <= 4e-6, worst
 
 
-def test_wino4_f4x4_opt_in_kernel(gpu):
+def test_wino4_f4x4_kernel(gpu):
     """conv3x3_wino4 (csrc/w2xc_wino4.hip): Winograd F(4x4,3x3) on the fp32 MFMA, the default mid-layer kernel since round 3 (layers with >= 64 output
     planes; the others take the F(2x2) kernels), here asked for through w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD4.  Same fp32 arithmetic type and the same
     north_star gate against the CPU oracle (rtol 1e-4 + atol 1e-5); its larger transform (interpolation points 0, +-3/4, +-3/2) costs ~1.3x the rounding error

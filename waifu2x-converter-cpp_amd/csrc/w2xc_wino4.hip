@@ -87,6 +87,24 @@ static __device__ __forceinline__ void bt6(float &x0, float &x1, float &x2, floa
     x5 = y5;
 }
 
+// the same in two halves (8 + 6 operations) with p, q, u, v carried in t[0..3]: a stage spreads them over two groups of MFMAs
+static __device__ __forceinline__ void bt6a(float &x0, float x1, float x2, float x3, float x4, float (&t)[4])
+{
+    x0 = __builtin_fmaf(-2.8125f, x2, __builtin_fmaf(1.265625f, x0, x4));
+    t[0] = __builtin_fmaf(-2.25f, x2, x4);
+    t[1] = __builtin_fmaf(-1.6875f, x1, 0.75f * x3);
+    t[2] = __builtin_fmaf(-0.5625f, x2, x4);
+    t[3] = __builtin_fmaf(-0.84375f, x1, 1.5f * x3);
+}
+static __device__ __forceinline__ void bt6b(float &x1, float &x2, float &x3, float &x4, float &x5, const float (&t)[4])
+{
+    x5 = __builtin_fmaf(-2.8125f, x3, __builtin_fmaf(1.265625f, x1, x5));
+    x1 = t[0] + t[1];
+    x2 = t[0] - t[1];
+    x3 = t[2] + t[3];
+    x4 = t[2] - t[3];
+}
+
 // y = A^T m for a 6-vector (12 fma / mul / add)
 static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2, float &y3)
 {
@@ -322,6 +340,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         constexpr int g = decltype(G_)::value;
         if constexpr (!(W4_ABL & 3)) bt6(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5]);
     };
+    float tq[4];
+    auto pass6h = [&](auto H_) {                                   // half-pass H = 2 g + {0, 1} of row / column g
+        constexpr int hh = decltype(H_)::value, g = hh >> 1;
+        if constexpr (!(W4_ABL & 3)) {
+            if constexpr ((hh & 1) == 0) bt6a(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], tq);
+            else bt6b(dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5], tq);
+        }
+    };
     using CT = std::true_type;
     using CF = std::false_type;
     // the quads a quarter touches: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
@@ -455,6 +481,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 tr_writes(C0{}, C6{});
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // W4P_SVC = 3: the work spread EVENLY, one portion behind the fourth MFMA of every group of four -- the two waves of a SIMD then fall into
+            // opposite phases by themselves (the older wave wins every arbitration for the matrix pipe, so the younger one issues its MFMAs while
+            // the older one is in a portion, and its own portions while the older one multiplies)
+            auto portion = [&](auto G_) {
+                constexpr int g = decltype(G_)::value;
+                if constexpr (g < 4 && !(W4_ABL & 16)) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, G_);
+                if constexpr (g == 4 && !(W4_ABL & 16)) { if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, G_); }
+                if constexpr (g == 5 && !(W4_ABL & 32)) dma_raw(C0{}, r1, r_slice);
+                if constexpr (g == 6 && !(W4_ABL & 32)) { if (wave < 3) dma_raw(C1{}, r1, r_slice); }
+                if constexpr (g == 0) tr_mask();
+                if constexpr (g < 6) pass6h(G_);
+                if constexpr (g == 6) tr_writes(C0{}, C6{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
             constexpr int SVC_XI = W4P_SVC == 1 ? 0 : (W4P_SVC == 2 ? (BT == 0 ? 32 : 0) : -1);
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
@@ -486,6 +526,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 if constexpr (W4P_NOP >= 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
                 if constexpr (W4P_NOP2 != 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (W4P_SVC == 3) {
+                    if constexpr (xi == 0) {
+                        tr_reads();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr ((xi & 3) == 3 && xi < 28) portion(std::integral_constant<int, (xi >> 2)>{});
+                }
                 // the stage's other work (W4P_SVC = 0: spread over the first MFMA slots)
                 if constexpr (W4P_SVC == 0) {
                     if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
