@@ -9,6 +9,7 @@
 // A tiny persistent pool: copy_rows() splits one strided row copy into `parts` contiguous row ranges,
 // the caller takes part in its own job, idle workers help.  Several device threads may submit at once.
 #pragma once
+#include <sched.h>
 #include <pthread.h>
 #include <atomic>
 #include <condition_variable>
@@ -68,6 +69,8 @@ public:
         }();
         return *p;
     }
+    // create the workers up to `n` now (callers that are about to bind threads to a NUMA node call this first)
+    void reserve(int n) { if (n > 0 && !forked().load(std::memory_order_relaxed)) ensure_threads(n); }
     static std::atomic<bool> &forked()
     {
         static std::atomic<bool> f{false};
@@ -106,6 +109,9 @@ public:
     }
 
 private:
+    CopyPool() { have_base_ = sched_getaffinity(0, sizeof base_, &base_) == 0; }
+    cpu_set_t base_;
+    bool have_base_ = false;
     struct Job {
         char *dst; size_t ds; const char *src; size_t ss; size_t rb; int rows, parts;
         std::atomic<int> next{0}, done{0};
@@ -146,6 +152,9 @@ private:
 
     void worker()
     {
+        // The pool is global and serves every device's pipeline: a worker must not keep the NUMA binding of whichever (bound) thread happened to
+        // create it.  Its affinity is reset to the mask the process had when the pool was built.
+        if (have_base_) sched_setaffinity(0, sizeof base_, &base_);
         for (;;) {
             std::shared_ptr<Job> j;
             // jobs arrive in bursts (one per staged chunk, ~100 us apart while a plane streams through the rings): poll for

@@ -831,6 +831,54 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 }
                 break;
             }
+            // fp32, host pipeline, last layer NOT fused: the last layer (0.8 ms on the 2160x3840 frame) is too short to hide the band's 33 MB download +
+            // stitch behind.  So layer n-1 and the last layer run TOGETHER in row chunks: chunk j's output rows leave for the host under layer n-1 of
+            // chunk j+1.  The producer chunks are whole 16-row tiles of the SAME tile grid as the unchunked launch (bit-identical results, nothing is
+            // computed twice); the last layer follows two rows behind (it reads rows y .. y + 2 of the producer's region).
+            if (hk && T == 0 && k == n - 1 && n >= 2 && kind == W2XC_K_MFMA && d.out_terms == 0 && last_kind == W2XC_K_LAST && last_direct &&
+                hk->out_chunk_rows > 0 && hk->output_ready && (y1 - y0) >= 256) {
+                if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
+                W2xcConvDesc dl;
+                memset(&dl, 0, sizeof dl);
+                dl.in = d.out; dl.in_rs = d.out_rs; dl.in_ps = d.out_ps; dl.in_cs = d.out_cs;
+                dl.in_h = d.out_h; dl.in_w = d.out_w;
+                dl.out_w = w;
+                dl.out_rs = (long long)out_stride_f; dl.out_ps = 1; dl.out_cs = out_cs;
+                const int off_l = y0 - 1 - Tk;   // rows of the producer's region above the last layer's first input row (0 on the one-row-per-layer geometry)
+                const int RL = d.out_h, R = y1 - y0;
+                // three producer launches -- 1/2, then 5/16, then the rest -- of whole 16-row tiles: every launch of the persistent kernel has a ramp and a tail
+                // (measured: four equal chunks cost layer 6 +0.6 ms on the 2160x3840 frame), while what the LAST chunk writes cannot hide behind compute
+                for (int p0 = 0, o0 = 0, ci = 0; p0 < RL; ci++) {
+                    const int want = ci == 0 ? RL / 2 : ci == 1 ? (RL * 5) / 16 : RL;
+                    int p1 = std::min(RL, p0 + std::max(64, (want + 15) & ~15));
+                    if (RL - p1 < 64) p1 = RL;
+                    W2xcConvDesc dd = d;
+                    dd.out_h = p1 - p0;
+                    dd.off_y = d.off_y + p0;
+                    dd.out = d.out + (size_t)p0 * d.out_rs;
+                    int rc = launch_layer(c, m, k - 1, kind, dd, st, o);
+                    if (rc) return rc;
+                    const int o1 = p1 == RL ? R : std::min(R, std::max(o0, p1 - off_l - 2));   // output rows whose three input rows exist
+                    // the LAST chunk's rows in pieces of ~128: what nothing can hide is then the download + stitch of the last piece only
+                    const int piece = (p1 == RL && o1 - o0 > 192) ? 128 : std::max(o1 - o0, 1);
+                    for (int a = o0; a < o1;) {
+                        int b = std::min(o1, a + piece);
+                        if (o1 - b < 64) b = o1;
+                        W2xcConvDesc dg = dl;
+                        dg.out_h = b - a;
+                        dg.off_y = off_l + a;
+                        dg.out = d_out + (size_t)(y0 - ra + a) * out_stride_f;
+                        rc = launch_layer(c, m, n - 1, W2XC_K_LAST, dg, st, o);
+                        if (rc) return rc;
+                        rc = hk->output_ready(y0 + a, y0 + b);
+                        if (rc) return rc;
+                        a = b;
+                    }
+                    p0 = p1;
+                    o0 = o1;
+                }
+                break;
+            }
             if (hk && k == n && hk->prefetch && y1 < rb) {   // stage the next band's input while this one computes
                 int rc = hk->prefetch(y1, std::min(rb, y1 + band));
                 if (rc) return rc;
@@ -1308,14 +1356,14 @@ int pipe_reserve(HostPipe &p, size_t in_bytes, size_t out_bytes, size_t in_slot,
     if (in_slot && p.in_slot_bytes < in_slot) {
         int rc = drain(); if (rc) return rc;
         if (p.pin_in) { HIP_TRY(hipHostFree(p.pin_in)); p.pin_in = nullptr; p.in_slot_bytes = 0; }
-        if (hipHostMalloc((void **)&p.pin_in, in_slot * HostPipe::IN_SLOTS, hipHostMallocNumaUser) != hipSuccess)
+        if (hipHostMalloc((void **)&p.pin_in, in_slot * HostPipe::IN_SLOTS, hipHostMallocDefault) != hipSuccess)
             return fail(W2XC_ERR_NOMEM, "hipHostMalloc of the input staging ring failed");
-        p.in_slot_bytes = in_slot;   // (hipHostMallocNumaUser: the pages follow the allocating thread's policy -- it is bound to the device's node)
+        p.in_slot_bytes = in_slot;   // (default policy: ROCm places pinned host memory near the allocating device)
     }
     if (out_slot && p.out_slot_bytes < out_slot) {
         int rc = drain(); if (rc) return rc;
         if (p.pin_out) { HIP_TRY(hipHostFree(p.pin_out)); p.pin_out = nullptr; p.out_slot_bytes = 0; }
-        if (hipHostMalloc((void **)&p.pin_out, out_slot * HostPipe::OUT_SLOTS, hipHostMallocNumaUser) != hipSuccess)
+        if (hipHostMalloc((void **)&p.pin_out, out_slot * HostPipe::OUT_SLOTS, hipHostMallocDefault) != hipSuccess)
             return fail(W2XC_ERR_NOMEM, "hipHostMalloc of the output staging ring failed");
         p.out_slot_bytes = out_slot;
     }
@@ -1612,9 +1660,11 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
             in_row0 = s0;
         }
     }
-    // modelUtility's nJob (modelHandler.hpp:99; the CLI's -j) = host threads that move rows in and out of the staging rings
-    // (at least two per unit: with the default nJob = 4 and 8 devices a single thread per device could not keep a 64 GB/s link busy)
-    const int copy_threads = std::max(nd > 1 ? 2 : 1, std::min(w2xc_get_jobs(), 32) / nd);
+    // modelUtility's nJob (modelHandler.hpp:99; the CLI's -j) = host threads that move rows in and out of the staging rings, shared by the units
+    const int copy_threads = std::max(1, std::min(w2xc_get_jobs(), 32) / nd);   // nJob bounds the total: never more than nJob staging threads over all units
+    // the pool's workers are created HERE, on the caller's (unbound) thread: a unit's feeder binds itself to its device's NUMA node, and workers created
+    // lazily from there would keep that node's mask while serving every device
+    w2xc_host::CopyPool::get().reserve(std::min(w2xc_get_jobs(), 32) - 1);
 
     int prev = 0;
     hipGetDevice(&prev);
