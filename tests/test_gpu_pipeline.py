@@ -357,3 +357,24 @@ def test_bench_two_ranks_shard_one_plane_on_the_hip_path(gpu, tmp_path):
     layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
     want = orc.Oracle(layers).convert(nn2x(synth_luma(2, 96, 128)), njob=8)
     assert_close(got, want, "2-rank sharded plane")
+
+
+def test_bench_eight_ranks_shard_one_plane_bit_identical_to_one_rank(gpu, tmp_path):
+    """N = 8 without an 8-GPU node: eight ranks (gloo for the barrier) share this GPU and row-shard ONE plane exactly as `bench.py --gpus 8` does on a
+    node -- every rank its rows plus the 28-row halo conv3x3_wino4's band geometry wants (4 rows per layer) -- and the eight shards, stitched, are
+    BIT-identical to the plane one rank computes alone.  The record's self-checks (ranks_seen, per-rank times, devices) hold for N = 8."""
+    d8, d1 = str(tmp_path / "d8"), str(tmp_path / "d1")
+    args = ["--workload", "plane", "--height", "1024", "--width", "768", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    j8 = run_bench(args + ["--dump-out", d8], env={"W2XC_BENCH_BACKEND": "gloo"}, nproc=8, timeout=1500)
+    assert j8["n_gpus"] == 8 and j8["ranks_seen"] == 8 and j8["scaling"] == "strong" and j8["config"]["frames_per_step"] == 1
+    assert len(j8["rank_ms_per_step"]) == 8 and all(v > 0 for v in j8["rank_ms_per_step"]) and len(j8["rank_devices"]) == 8
+    assert j8["host_to_host"]["max_abs_diff_vs_resident_output"] == 0.0 and j8["output_finite"]
+    parts = [np.load(os.path.join(d8, "rank%d.npz" % r)) for r in range(8)]
+    assert int(parts[0]["ra"]) == 0 and int(parts[7]["rb"]) == 2048 and all(int(parts[r]["rb"]) == int(parts[r + 1]["ra"]) for r in range(7))
+    got = np.concatenate([p["rows"] for p in parts])
+    j1 = run_bench(args + ["--dump-out", d1])
+    one = np.load(os.path.join(d1, "rank0.npz"))
+    assert int(one["ra"]) == 0 and int(one["rb"]) == 2048 and j1["ranks_seen"] == 1
+    assert np.array_equal(got, one["rows"]), "8 row shards != the plane of one rank (max |diff| %g)" % float(np.abs(got - one["rows"]).max())
+    h = j8["host_to_host"]
+    print("8 ranks on one device, 2048x1536 plane: resident %.2f ms per step, host gather %s" % (j8["ms_per_step"], {k: v for k, v in h.items() if isinstance(v, dict)}))
