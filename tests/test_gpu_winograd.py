@@ -91,10 +91,12 @@ def test_winograd_vs_oracle(gpu, planes, name):
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("mid", ["conv3x3_wino4", "conv3x3_wino16"])
 @pytest.mark.parametrize("planes", [[1, 32, 32, 64, 64, 128, 128, 1], [1, 32, 64, 1], [1, 64, 128, 64, 1], [1, 32, 128, 1]])
-def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
-    """N3 on the fp32 path: the one-plane last layer inside conv3x3_wino16's epilogue (taps-as-rows MFMAs on the activations the epilogue
-    has just produced; Cout / 32 x 9 partial tap planes + conv3x3_last_gather) against the separate conv3x3_last launch
+def test_fused_last_layer_fp32_vs_unfused(gpu, planes, mid):
+    """N3 on the fp32 path: the one-plane last layer inside the epilogue of the DEFAULT kernel conv3x3_wino4 (taps-as-rows MFMAs on the activations the
+    epilogue has just produced, the four plane tiles of a 64-plane block summed on chip: Cout / 64 x 9 partial tap planes + conv3x3_last_gather) and of
+    conv3x3_wino16 (W2XC_KERNEL_WINOGRAD: Cout / 32 x 9 interleaved partials) against the separate conv3x3_last launch
     (w2xc_opts.fusion = W2XC_FUSION_ON / _OFF) and against the CPU oracle.  Same fp32 arithmetic type, the last layer's channel sum
     split in 32-plane partials: the two runs agree to the level two fp32 summation orders do.  Odd sizes, planes smaller than a
     work item, banding (bit-identical inside the fused run), the nearest-2x entry and the host pipeline's chunked path (>= 128 rows)."""
@@ -103,9 +105,13 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
     layers = gen_model.synth_layers(planes, 77 + len(planes))
     ms = gpu._ModelSet.from_layers(layers)
     n = len(planes) - 1
-    on, off = gpu.make_opts(fusion=gpu.FUSION_ON), gpu.make_opts(fusion=gpu.FUSION_OFF)
-    assert ms.kernel_name(n - 1, on) == "conv3x3_last_gather" and ms.kernel_name(n - 2, on) == "conv3x3_wino16"
+    kern = gpu.KERNEL_WINOGRAD4 if mid == "conv3x3_wino4" else gpu.KERNEL_WINOGRAD
+    on, off = gpu.make_opts(fusion=gpu.FUSION_ON, kernel=kern), gpu.make_opts(fusion=gpu.FUSION_OFF, kernel=kern)
+    assert ms.kernel_name(n - 1, on) == "conv3x3_last_gather" and ms.kernel_name(n - 2, on) == mid
     assert ms.kernel_name(n - 1, off) == "conv3x3_last"
+    if mid == "conv3x3_wino4":   # ... and it is what the default options run
+        assert ms.kernel_name(n - 1) == "conv3x3_last_gather" and ms.kernel_name(n - 2) == mid
+    gate = 4e-5 if mid == "conv3x3_wino4" else 1e-5   # (max-norm gates of the two kernels, test_wino4_f4x4_kernel / test_winograd16)
     o = orc.Oracle(layers)
     worst = 0.0
     for (h, wd) in ((37, 61), (8, 32), (300, 170), (1, 1), (16, 33)):
@@ -113,9 +119,9 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes):
         a, b = ms.convert(x, opts=on), ms.convert(x, opts=off)
         worst = max(worst, float(np.abs(a - b).max() / np.abs(b).max()))
         for band in (1, 7, 64):
-            assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(fusion=gpu.FUSION_ON, band_rows=band))), ("banding", planes, h, wd, band)
+            assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(fusion=gpu.FUSION_ON, kernel=kern, band_rows=band))), ("banding", planes, h, wd, band)
         want = o.convert(x, njob=8)
-        assert np.allclose(a, want, rtol=1e-4, atol=1e-5) and np.abs(a - want).max() <= 1e-5 * np.abs(want).max()
+        assert np.allclose(a, want, rtol=1e-4, atol=1e-5) and np.abs(a - want).max() <= gate * np.abs(want).max()
         a2, b2 = ms.convert_nn2x(x, opts=on), ms.convert_nn2x(x, opts=off)
         worst = max(worst, float(np.abs(a2 - b2).max() / np.abs(b2).max()))
     print("fused vs unfused last layer, %s: max err %.2e of the output range" % (planes, worst))

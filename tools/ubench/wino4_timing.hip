@@ -32,6 +32,35 @@ __global__ void ref_check(const float *in, long long irs, long long ics, long lo
     if (!(err <= 1e-5 + 1e-4 * fabs(acc))) atomicAdd(nbad, 1ull);
 }
 
+// fused last layer: G[ob][tap][y][x] = sum over the 64 planes of block ob of w7[plane][tap] * leaky(bias + conv(in)[plane]) -- against a double-precision sum
+__global__ void ref_check_fused(const float *in, long long irs, long long ics, long long ips, const float *w, const float *bias, const float *w7, const float *G,
+                                long long gts, long long ggs, long long grs, int cin, int cout, int h, int wd, int nsamp, int off_y, double *maxerr, double *maxref,
+                                unsigned long long *nbad)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsamp) return;
+    unsigned r = 2654435761u * (unsigned)(idx + 1);
+    const int x = (int)(r % (unsigned)wd); r = r * 1664525u + 1013904223u;
+    const int y = (int)((r >> 8) % (unsigned)h); r = r * 1664525u + 1013904223u;
+    const int tap = (int)((r >> 8) % 9u); r = r * 1664525u + 1013904223u;
+    const int ob = (int)((r >> 8) % (unsigned)(cout / 64));
+    double sum = 0.0;
+    for (int o = ob * 64; o < ob * 64 + 64; o++) {
+        double acc = 0.0;
+        for (int c = 0; c < cin; c++)
+            for (int rr = 0; rr < 3; rr++)
+                for (int q = 0; q < 3; q++) acc += (double)w[((size_t)o * cin + c) * 9 + rr * 3 + q] * (double)in[c * ics + (long long)(y + off_y + rr) * irs + (x + q) * ips];
+        acc += (double)bias[o];
+        acc = acc > 0 ? acc : 0.1 * acc;
+        sum += (double)w7[o * 9 + tap] * acc;
+    }
+    const double got = (double)G[ob * gts + tap * ggs + (long long)y * grs + x];
+    const double err = fabs(got - sum);
+    atomicMax(reinterpret_cast<unsigned long long *>(maxerr), (unsigned long long)__double_as_longlong(err));
+    atomicMax(reinterpret_cast<unsigned long long *>(maxref), (unsigned long long)__double_as_longlong(fabs(sum)));
+    if (!(err <= 2e-5 + 1e-4 * fabs(sum))) atomicAdd(nbad, 1ull);
+}
+
 int main(int argc, char **argv)
 {
     const int cin = argc > 1 ? atoi(argv[1]) : 128, cout = argc > 2 ? atoi(argv[2]) : 128;
@@ -40,6 +69,7 @@ int main(int argc, char **argv)
     const int wino_py = argc > 6 ? atoi(argv[6]) : 0, off_y = argc > 7 ? atoi(argv[7]) : 0;   // (block phase of the first row; rows skipped in the input)
     const int ih = h + 2 + off_y + (argc > 8 ? atoi(argv[8]) : 0), iw = w + 2;
     const int nhwc_in = argc > 9 ? atoi(argv[9]) : 0;   // (cin = 32 only)
+    const int fuse = argc > 10 ? atoi(argv[10]) : 0;     // the one-plane last layer in the epilogue: the output is the partial tap planes
     const long long irs = nhwc_in ? (long long)iw * cin : (iw + 3) & ~3, ics = nhwc_in ? 1 : irs * ih, ips = nhwc_in ? cin : 1;
     const long long ors_p = (w + 3) & ~3, ocs_p = ors_p * h;
     std::vector<float> hin(nhwc_in ? (size_t)irs * ih : (size_t)ics * cin), hw((size_t)cout * cin * 9), hb(cout);
@@ -56,7 +86,7 @@ int main(int argc, char **argv)
     std::vector<float> pk((size_t)36 * cin * cout);
     w2xc_wino4_pack(cin, cout, hw.data(), pk.data());
     float *din, *dout, *dw, *dwraw, *db;
-    const size_t out_floats = nhwc_out ? (size_t)h * w * cout : (size_t)ocs_p * cout;
+    const size_t out_floats = fuse ? (size_t)(cout / 64) * 9 * h * w : nhwc_out ? (size_t)h * w * cout : (size_t)ocs_p * cout;
     hipMalloc(&din, hin.size() * 4); hipMalloc(&dout, out_floats * 4); hipMalloc(&dw, pk.size() * 4); hipMalloc(&db, cout * 4); hipMalloc(&dwraw, hw.size() * 4);
     hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice);
@@ -70,16 +100,36 @@ int main(int argc, char **argv)
     if (nhwc_out) { d.out_rs = (long long)w * cout; d.out_ps = cout; d.out_cs = 1; }
     else { d.out_rs = ors_p; d.out_ps = 1; d.out_cs = ocs_p; }
     d.in_h = ih; d.in_w = iw; d.out_h = h; d.out_w = w; d.wino_py = wino_py; d.off_y = off_y;
+    std::vector<float> hw7((size_t)cout * 9), pk7(w2xc_wino4_pack_last_floats(cout));
+    float *dw7 = nullptr, *dw7raw = nullptr;
+    if (fuse) {
+        for (auto &v : hw7) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
+        w2xc_wino4_pack_last(cout, hw7.data(), pk7.data());
+        hipMalloc(&dw7, pk7.size() * 4); hipMalloc(&dw7raw, hw7.size() * 4);
+        hipMemcpy(dw7, pk7.data(), pk7.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dw7raw, hw7.data(), hw7.size() * 4, hipMemcpyHostToDevice);
+        d.out_terms = 9; d.w7pk = dw7; d.out_rs = w; d.out_ps = 1; d.out_gs = (long long)h * w; d.out_ts = 9 * d.out_gs;
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 4; rep++) {
         hipEventRecord(e0);
         hipError_t e = w2xc_launch_wino4(d, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("wino4 %d->%d %dx%d %s py %d off_y %d: %.3f ms (%s / %s)\n", cin, cout, h, w, nhwc_out ? "nhwc-out" : "planar-out", wino_py, off_y, ms, hipGetErrorString(e), hipGetErrorString(hipGetLastError()));
+        printf("wino4 %d->%d %dx%d %s py %d off_y %d: %.3f ms (%s / %s)\n", cin, cout, h, w, fuse ? "fused-last" : nhwc_out ? "nhwc-out" : "planar-out", wino_py, off_y, ms, hipGetErrorString(e), hipGetErrorString(hipGetLastError()));
     }
 #if W4_ABL == 0
-    {
+    if (fuse) {
+        double *dm; unsigned long long *dbad;
+        hipMalloc(&dm, 16); hipMalloc(&dbad, 8); hipMemset(dm, 0, 16); hipMemset(dbad, 0, 8);
+        const int nsamp = h * w * 9 > 40000 ? 40000 : h * w * 9;
+        hipLaunchKernelGGL(ref_check_fused, dim3((nsamp + 255) / 256), dim3(256), 0, 0, din, irs, ics, ips, dwraw, db, dw7raw, dout, d.out_ts, d.out_gs, d.out_rs, cin, cout, h, w,
+                           nsamp, off_y, dm, dm + 1, dbad);
+        double hm[2]; unsigned long long bad;
+        hipMemcpy(hm, dm, 16, hipMemcpyDeviceToHost); hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost);
+        printf("fused check (%d samples of the partial tap planes): max |err| %.3g, max |ref| %.3g, outside 2e-5 + 1e-4 |ref|: %llu  %s\n", nsamp, hm[0], hm[1], bad,
+               bad == 0 && hm[1] > 0 ? "OK" : "FAILED");
+    } else {
         double *dm; unsigned long long *dbad;
         hipMalloc(&dm, 16); hipMalloc(&dbad, 8); hipMemset(dm, 0, 16); hipMemset(dbad, 0, 8);
         const int ystep = h > 600 ? 7 : 1, xstep = w > 600 ? 5 : 1;

@@ -88,6 +88,7 @@ struct DevLayer {
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
     float last_fused_scale[4] = {1, 1, 1, 1};
     float *w_last_wino16 = nullptr;   // w2xc_wino16_pack_last image (fp32 path: last layer inside conv3x3_wino16's epilogue)
+    float *w_last_wino4 = nullptr;    // w2xc_wino4_pack_last image (fp32 path: last layer inside conv3x3_wino4's epilogue)
     float *bias = nullptr;
 };
 
@@ -182,6 +183,7 @@ struct DevCtx {
             if (l.w_wino16) hipFree(l.w_wino16);
             if (l.w_wino4) hipFree(l.w_wino4);
             if (l.w_last_wino16) hipFree(l.w_last_wino16);
+            if (l.w_last_wino4) hipFree(l.w_last_wino4);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
             for (float *p : l.w_last_fused)
@@ -274,6 +276,7 @@ int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o);
+bool is_wino4_layer(const w2xc_model *m, int l, const w2xc_opts &o);
 int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o);
 bool uses_wino4(const w2xc_model *m, const w2xc_opts &o);
 bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o);
@@ -334,7 +337,7 @@ int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
 }
 
 // partial-G planes a fused-last producer writes per tap: wave columns of the split tile shapes, 32-plane blocks of conv3x3_wino16
-int fused_halves(int T, int cout) { return T > 0 ? w2xc_split_halves(T, cout) : cout / 32; }
+int fused_halves(int T, int cout, bool wino4 = false) { return T > 0 ? w2xc_split_halves(T, cout) : wino4 ? cout / 64 : cout / 32; }
 
 int upload(const std::vector<float> &h, float **d)
 {
@@ -445,13 +448,11 @@ int mid_variant_for(int midv, int cin, int cout)
     return midv;
 }
 
-// the variant mid layer l really runs with these options.  An EXPLICIT request for the fused last layer (w2xc_opts.fusion = W2XC_FUSION_ON) is served by
-// conv3x3_wino16, the kernel that has that epilogue, whatever the process default for the mid layers is.
+// the variant mid layer l really runs with these options (both conv3x3_wino4 and conv3x3_wino16 carry the fused last layer in their epilogue)
 int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     const HostLayer &p = m->layers[l];
     int midv = mid_variant(o);
-    if (midv == MID_WINO4 && o.kernel == W2XC_KERNEL_AUTO && o.fusion == W2XC_FUSION_ON && l == (int)m->layers.size() - 2) midv = MID_WINO16;
     return mid_variant_for(midv, p.nin, p.nout);
 }
 // does any layer of the fp32 path run conv3x3_wino4 (F(4x4,3x3))?  Its 4x4 blocks make results depend on where a band's per-layer regions end,
@@ -493,7 +494,8 @@ bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
     if (o.fusion == W2XC_FUSION_OFF || (o.fusion != W2XC_FUSION_ON && !env_default)) return false;
     const HostLayer &p = m->layers[n - 2], &q = m->layers[n - 1];
     if (q.nout != 1 || q.nin != p.nout || w2xc_pick_kernel(q.nin, 1) != W2XC_K_LAST || w2xc_pick_kernel(p.nin, p.nout) != W2XC_K_MFMA) return false;
-    return layer_mid_variant(m, n - 2, o) == MID_WINO16;
+    const int v = layer_mid_variant(m, n - 2, o);
+    return v == MID_WINO16 || v == MID_WINO4;
 }
 
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
@@ -550,13 +552,23 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         d.wpk = img;
         if (d.out_terms == 9) {   // the next (last) layer's weights ride along (fuse_last_fp32)
             DevLayer &nl = c->layers[l + 1];
-            if (!nl.w_last_wino16) {
-                std::vector<float> pk(w2xc_wino16_pack_last_floats(m->layers[l + 1].nin));
-                w2xc_wino16_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
-                int rc = upload(pk, &nl.w_last_wino16);
-                if (rc) return rc;
+            if (midv == MID_WINO4) {
+                if (!nl.w_last_wino4) {
+                    std::vector<float> pk(w2xc_wino4_pack_last_floats(m->layers[l + 1].nin));
+                    w2xc_wino4_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
+                    int rc = upload(pk, &nl.w_last_wino4);
+                    if (rc) return rc;
+                }
+                d.w7pk = nl.w_last_wino4;
+            } else {
+                if (!nl.w_last_wino16) {
+                    std::vector<float> pk(w2xc_wino16_pack_last_floats(m->layers[l + 1].nin));
+                    w2xc_wino16_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
+                    int rc = upload(pk, &nl.w_last_wino16);
+                    if (rc) return rc;
+                }
+                d.w7pk = nl.w_last_wino16;
             }
-            d.w7pk = nl.w_last_wino16;
         }
     }
     d.bias = dl.bias;
@@ -656,7 +668,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
             const size_t hk = (size_t)rows + ((HL == 1 || k == n) ? 2 * (n - k) : 6 + 8 * (n - k)), wk = (size_t)w + 2 * (n - k);
             const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
-            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
+            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout, is_wino4_layer(m, k - 1, o)) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
             const size_t wk_mem = planar_between(m, k - 1, o) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows start on 128-byte lines
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk_mem * px_bytes);
         }
@@ -778,8 +790,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     d.out_rs = d.out_w; d.out_ps = 1;
                     d.out_gs = (long long)d.out_h * d.out_w;
                     d.out_ts = 9 * d.out_gs;
-                    d.halves = fused_halves(T, hl.nout);
-                    if (T == 0) {   // fp32 (conv3x3_wino16): the partials interleaved, G[tap][y][x][half] -- the gather reads 16 bytes per tap and pixel
+                    d.halves = fused_halves(T, hl.nout, is_wino4_layer(m, k - 1, o));
+                    if (T == 0 && !is_wino4_layer(m, k - 1, o)) {   // fp32, conv3x3_wino16: the partials interleaved, G[tap][y][x][half] -- the gather reads 16 bytes per tap and pixel
+                        // (conv3x3_wino4 writes planar partial planes G[64-plane block][tap][y][x]: its epilogue sums the four plane tiles of a block on chip)
                         d.out_ps = d.halves; d.out_rs = (long long)d.out_w * d.halves;
                         d.out_gs = (long long)d.out_h * d.out_w * d.halves;
                         d.out_ts = 1;
@@ -835,7 +848,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             // stitch behind.  So layer n-1 and the last layer run TOGETHER in row chunks: chunk j's output rows leave for the host under layer n-1 of
             // chunk j+1.  The producer chunks are whole 16-row tiles of the SAME tile grid as the unchunked launch (bit-identical results, nothing is
             // computed twice); the last layer follows two rows behind (it reads rows y .. y + 2 of the producer's region).
-            if (hk && T == 0 && k == n - 1 && n >= 2 && kind == W2XC_K_MFMA && d.out_terms == 0 && last_kind == W2XC_K_LAST && last_direct &&
+            const bool tail_unfused = d.out_terms == 0 && last_kind == W2XC_K_LAST;
+            const bool tail_fused4 = d.out_terms == 9 && last_kind == W2XC_K_LAST_GATHER && is_wino4_layer(m, k - 1, o);   // (conv3x3_wino4's fused epilogue + gather)
+            if (hk && T == 0 && k == n - 1 && n >= 2 && kind == W2XC_K_MFMA && (tail_unfused || tail_fused4) && last_direct &&
                 hk->out_chunk_rows > 0 && hk->output_ready && (y1 - y0) >= 256) {
                 if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
                 W2xcConvDesc dl;
@@ -868,7 +883,13 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                         dg.out_h = b - a;
                         dg.off_y = off_l + a;
                         dg.out = d_out + (size_t)(y0 - ra + a) * out_stride_f;
-                        rc = launch_layer(c, m, n - 1, W2XC_K_LAST, dg, st, o);
+                        if (tail_fused4) {   // the gather has no offsets: its input view starts at the partial planes' row off_l + a
+                            dg.in = d.out + (size_t)(off_l + a) * d.out_rs;
+                            dg.in_ts = d.out_ts; dg.in_gs = d.out_gs; dg.halves = d.halves;
+                            dg.in_h = b - a + 2;
+                            dg.off_y = 0;
+                        }
+                        rc = launch_layer(c, m, n - 1, last_kind, dg, st, o);
                         if (rc) return rc;
                         rc = hk->output_ready(y0 + a, y0 + b);
                         if (rc) return rc;

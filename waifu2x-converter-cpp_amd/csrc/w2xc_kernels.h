@@ -86,6 +86,10 @@ bool w2xc_wino16_supported(int cin, int cout);
 bool w2xc_wino4_supported(int cin, int cout);
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
+// d.out_terms = 9: the one-plane LAST layer in conv3x3_wino4's epilogue; d.w7pk = w2xc_wino4_pack_last image, `out` = partial tap planes
+// G[64-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 64
+size_t w2xc_wino4_pack_last_floats(int cin);
+void w2xc_wino4_pack_last(int cin, const float *w, float *dst);
 void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,

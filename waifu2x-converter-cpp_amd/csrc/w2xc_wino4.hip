@@ -144,7 +144,7 @@ static constexpr __host__ __device__ int w4p_quad(int kind, int n)
 
 }   // namespace
 
-template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false>
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tiles_x, int nitems)
 {
     constexpr int ROWS = 16;
@@ -590,6 +590,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                                       : d.out + (long long)oy * d.out_rs + (long long)ox * COUT + plane0;
             const bool interior = ty0 >= 0 && ty0 + ROWS <= d.out_h && tile_x * 32 + 32 <= d.out_w;   // wave-uniform
             const f32x4 bq = *reinterpret_cast<const f32x4 *>(ldsb + BIAS_BASE + plane0 * 4);
+            // FUSE7: the one-plane LAST layer (convertRoutine.cpp:66-76's next iteration) inside this epilogue, "taps as rows": per pixel the nine partial
+            // sums T_tap = sum over this wave's 16 planes of w7[plane][tap] * a6[plane] on the MFMA (A = w7 of the planes 4 k + e as 16 x 4, tap = row;
+            // B = the activations just computed, lane (k, block) = plane 4 k + e of a pixel of that block), summed over the four plane-tile waves
+            // through the V slot that is idle between two items, and written as 9 tap planes per 64-plane block: 72 bytes per pixel leave the chip
+            // instead of 512, and conv3x3_last_gather adds taps and blocks (0.1 ms instead of the 0.8 ms of conv3x3_last).
+            float a7[4];
+            if constexpr (FUSE7) {
+                const float *w7 = reinterpret_cast<const float *>(d.w7pk) + (size_t)(ob * 4 + pt) * 256 + lane;   // [16-plane group][e][lane]
+#pragma unroll
+                for (int e = 0; e < 4; e++) a7[e] = w7[e * 64];
+            }
+            char *red = ldsb + V_BASE + v2;   // [pt][tap quad 0 / 1][128 pixels][4] (16 KiB) + [pt][128 pixels] for tap 8 (2 KiB)
             // Two output ROWS of the block at a time (the row transform of a column per row PAIR: 7 operations instead of 10 for all four rows):
             // 48 + 16 live values beside the 144 accumulators.
 #pragma unroll
@@ -621,10 +633,57 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         const float w0 = y0 + bq[e], w1 = y1 + bq[e], w2 = y2 + bq[e], w3 = y3 + bq[e];
                         const float l0 = __builtin_amdgcn_fmed3f(w0, 0.1f * w0, 3.402823466e+38f), l1 = __builtin_amdgcn_fmed3f(w1, 0.1f * w1, 3.402823466e+38f);
                         const float l2 = __builtin_amdgcn_fmed3f(w2, 0.1f * w2, 3.402823466e+38f), l3 = __builtin_amdgcn_fmed3f(w3, 0.1f * w3, 3.402823466e+38f);
-                        if constexpr (OUT_PLANAR) y[e] = f32x4{l0, l1, l2, l3};
+                        if constexpr (OUT_PLANAR || FUSE7) y[e] = f32x4{l0, l1, l2, l3};
                         else { y[0][e] = l0; y[1][e] = l1; y[2][e] = l2; y[3][e] = l3; }
                     }
-                    if constexpr ((W4_ABL & 64) != 0) {
+                    if constexpr (FUSE7) {
+                        // y[e] = the four pixels of row i of plane e (OUT_PLANAR form): D[j] = taps of pixel j of this lane's block over the wave's planes
+                        f32x4 D[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) D[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) D[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a7[e], y[e][j], D[j], 0, 0, 0);
+                        // lane (k, t) holds taps 4 k .. 4 k + 3 of pixel j of block t: pixel index p = (block row) * 32 + (block column) * 4 + j of the row slab
+                        const int p0 = (2 * bt + (t >> 3)) * 32 + (t & 7) * 4;
+                        if (k < 2) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4 *>(red + ((pt * 2 + k) * 128 + p0 + j) * 16) = D[j];
+                        } else if (k == 2) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) *reinterpret_cast<float *>(red + 16384 + (pt * 128 + p0 + j) * 4) = D[j][0];
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        {
+                            const int tid = threadIdx.x;
+                            if (tid < 384) {
+                                const int p = tid & 127, kq = tid >> 7;     // kq = 0, 1: taps 4 kq .. 4 kq + 3; kq = 2: tap 8
+                                const int gy = ty0 + 4 * (p >> 5) + i, gx = tile_x * 32 + (p & 31);
+                                const bool ok = gy >= 0 && gy < d.out_h && gx < d.out_w;
+                                float *g = d.out + (long long)ob * d.out_ts + (long long)gy * d.out_rs + gx;
+                                if (kq < 2) {
+                                    f32x4 sum = *reinterpret_cast<const f32x4 *>(red + ((0 * 2 + kq) * 128 + p) * 16);
+#pragma unroll
+                                    for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const f32x4 *>(red + ((q * 2 + kq) * 128 + p) * 16);   // (fixed order: reproducible)
+                                    if (ok) {
+#pragma unroll
+                                        for (int r = 0; r < 4; r++) g[(long long)(4 * kq + r) * d.out_gs] = sum[r];
+                                    }
+                                } else {
+                                    float sum = *reinterpret_cast<const float *>(red + 16384 + p * 4);
+#pragma unroll
+                                    for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const float *>(red + 16384 + (q * 128 + p) * 4);
+                                    if (ok) g[8 * d.out_gs] = sum;
+                                }
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();   // (the slab is rewritten by the next row; after the last row the next item's row passes park here)
+                        asm volatile("" ::: "memory");
+                    } else if constexpr ((W4_ABL & 64) != 0) {
                         if (y[0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0] + y[1] + y[2] + y[3];
                     } else if constexpr (OUT_PLANAR) {
                         // whole quads: the row stride holds roundup4(out_w) pixels (the launcher checks), columns >= out_w are never read as data
@@ -670,19 +729,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side.  Two objects (make -j): W2XC_WINO4_PART = 0 the planar-out instantiations + packer + dispatcher, 1 the NHWC-out ones.
+// host side.  Three objects (make -j): W2XC_WINO4_PART = 0 the planar-out instantiations + packers + dispatcher, 1 the NHWC-out ones, 2 the fused-last ones.
 // ------------------------------------------------------------------------------------------------
 #ifndef W2XC_WINO4_PART
 #define W2XC_WINO4_PART -1   // one translation unit with everything (tools/ubench)
 #endif
-template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false>
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false>
 static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 3) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 64);
     constexpr size_t lds_bytes = 3 * (size_t)(11 * 1024) + 2 * (size_t)(36 * 1024) + 3 * (size_t)(18 * 1024) + COUT * 4;   // raw + U + V + bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_wino4<CIN, COUT, OUT_PLANAR, IN_NHWC>;
+    auto kern = conv3x3_wino4<CIN, COUT, OUT_PLANAR, IN_NHWC, FUSE7>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -700,7 +759,7 @@ static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 
 
 hipError_t w2xc_launch_wino4_nhwc_out(const W2xcConvDesc &d, hipStream_t stream);
-#if W2XC_WINO4_PART != 0
+#if W2XC_WINO4_PART != 0 && W2XC_WINO4_PART != 2
 hipError_t w2xc_launch_wino4_nhwc_out(const W2xcConvDesc &d, hipStream_t stream)
 {
 #ifdef W4P_SINGLE
@@ -721,7 +780,42 @@ hipError_t w2xc_launch_wino4_nhwc_out(const W2xcConvDesc &d, hipStream_t stream)
 }
 #endif
 
-#if W2XC_WINO4_PART != 1
+// d.out_terms = 9: the one-plane last layer in the epilogue; `out` = partial tap planes G[64-plane block][tap][y][x] (out_ts / out_gs / out_rs),
+// d.w7pk = the w2xc_wino4_pack_last image of its weights; W2XC_K_LAST_GATHER finishes with halves = cout / 64
+hipError_t w2xc_launch_wino4_fused(const W2xcConvDesc &d, hipStream_t stream);
+#if W2XC_WINO4_PART != 0 && W2XC_WINO4_PART != 1
+hipError_t w2xc_launch_wino4_fused(const W2xcConvDesc &d, hipStream_t stream)
+{
+#ifdef W4P_SINGLE
+    return d.cin == 128 && d.cout == 128 && d.in_ps == 1 ? launch_wino4<128, 128, true, false, true>(d, stream) : hipErrorInvalidValue;
+#else
+    if (d.cin == 32 && d.in_ps == 32 && d.in_cs == 1)
+        return d.cout == 64 ? launch_wino4<32, 64, true, true, true>(d, stream) : d.cout == 128 ? launch_wino4<32, 128, true, true, true>(d, stream) : hipErrorInvalidValue;
+    switch (d.cin * 1000 + d.cout) {
+    case 64064:  return launch_wino4<64, 64, true, false, true>(d, stream);
+    case 64128:  return launch_wino4<64, 128, true, false, true>(d, stream);
+    case 128064: return launch_wino4<128, 64, true, false, true>(d, stream);
+    case 128128: return launch_wino4<128, 128, true, false, true>(d, stream);
+    default: return hipErrorInvalidValue;
+    }
+#endif
+}
+#endif
+
+#if W2XC_WINO4_PART == 0 || W2XC_WINO4_PART == -1
+// the last layer's weights as MFMA A fragments for conv3x3_wino4's fused epilogue: [16-plane group g][e][lane = 16 kk + m] = w7[plane 16 g + 4 kk + e][tap m]
+// (m < 9, else 0).  w is [1][cin][3][3] (modelHandler.cpp:102).  16 * cin floats.
+size_t w2xc_wino4_pack_last_floats(int cin) { return (size_t)16 * cin; }
+void w2xc_wino4_pack_last(int cin, const float *w, float *dst)
+{
+    for (int g = 0; g < cin / 16; g++)
+        for (int e = 0; e < 4; e++)
+            for (int kk = 0; kk < 4; kk++)
+                for (int m = 0; m < 16; m++) dst[((size_t)g * 4 + e) * 64 + kk * 16 + m] = m < 9 ? w[(size_t)(16 * g + 4 * kk + e) * 9 + m] : 0.0f;
+}
+#endif
+
+#if W2XC_WINO4_PART != 1 && W2XC_WINO4_PART != 2
 bool w2xc_wino4_supported(int cin, int cout)
 {
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
@@ -770,6 +864,11 @@ hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
     } else {
         if (d.in_ps != 1 || (d.in_cs & 3) != 0 || d.off_x < 0 || (d.off_x & 3) != 0 || d.in_rs < ((d.in_w + 3) & ~3)) return hipErrorInvalidValue;
         if (3 * d.in_cs * 4 + 24 * d.in_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit lane offsets inside a 4-channel slice of a tile
+    }
+    if (d.out_terms == 9) {   // fused last layer: partial tap planes, rows of out_w floats
+        if (d.cout != 64 && d.cout != 128) return hipErrorInvalidValue;
+        if (!d.w7pk || d.out_rs < d.out_w || d.out_gs < d.out_rs * (long long)d.out_h) return hipErrorInvalidValue;
+        return w2xc_launch_wino4_fused(d, stream);
     }
     const bool planar = d.out_ps == 1;
     if (planar) {
