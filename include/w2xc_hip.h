@@ -36,9 +36,10 @@ extern "C" {
  * (one w2xc::Model per conv layer, modelHandler.hpp:24-90). */
 typedef struct w2xc_model w2xc_model;
 
-#define W2XC_PRECISION_FP32 0   /* fp32 throughout on v_mfma_f32_32x32x2_f32: Winograd F(2x2,3x3) for the layers with 32 / 64 /
-                                 * 128 planes in and out (conv3x3_wino; W2XC_WINOGRAD=0 in the environment selects the
-                                 * exact-f32 fma chains of conv3x3_mfma2 instead); rtol 1e-4 vs the reference either way */
+#define W2XC_PRECISION_FP32 0   /* fp32 throughout on the fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2): Winograd F(4x4,3x3) for the layers
+                                 * with 64 / 128 output planes (conv3x3_wino4), F(2x2,3x3) for 32 output planes (conv3x3_wino); per call
+                                 * w2xc_opts.kernel = W2XC_KERNEL_MFMA selects the exact-f32 fma chains of conv3x3_mfma2 instead.
+                                 * rtol 1e-4 vs the reference either way                                                       */
 #define W2XC_PRECISION_BF16 1   /* w2xc_convert_* only: activations BETWEEN layers are bf16 (RNE), layers
                                  * 2..n-1 use bf16 weights on v_mfma_f32_32x32x16_bf16 with fp32
                                  * accumulate, bias and LeakyReLU; the first layer stays fp32, a one-plane
@@ -56,19 +57,20 @@ typedef struct w2xc_model w2xc_model;
                                  * layers 1..n-2 saturate at +-65504 and carry 2^-25 ABSOLUTE precision below
                                  * 2^-3 -- meant for image planes in [0, 1].                   */
 
-#define W2XC_KERNEL_AUTO    0   /* the fast kernel of each layer shape; for the fp32 layers with 32 / 64 / 128 planes in and out that
-                                 * is the process default: Winograd F(4x4,3x3) (conv3x3_wino4; F(2x2,3x3) where it does not apply: 32 output
-                                 * planes, or a row-band view without the wide halo below) unless the environment says W2XC_WINOGRAD=0
-                                 * (then W2XC_KERNEL_MFMA), W2XC_WINO_KERNEL=16 (W2XC_KERNEL_WINOGRAD) or =32 (W2XC_KERNEL_WINOGRAD32) */
+#define W2XC_KERNEL_AUTO    0   /* the fast kernel of each layer shape; for the fp32 layers with 32 / 64 / 128 planes in and out that is
+                                 * W2XC_KERNEL_WINOGRAD4.  On a row-band view WITHOUT the wide halo below (w2xc_convert_rows_device /
+                                 * w2xc_convert_plane_rows) it runs the banding-invariant F(2x2) kernels instead (same tolerance,
+                                 * another rounding).  No environment switches: the choice is the caller's, per call.            */
 #define W2XC_KERNEL_DIRECT  1   /* every layer: reference-ordered direct conv on VALU (bit-exact vs the oracle)             */
 #define W2XC_KERNEL_MFMA    2   /* mid layers: direct implicit GEMM, a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32
                                  * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
 #define W2XC_KERNEL_WINOGRAD 3  /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (conv3x3_wino16), fp32 throughout */
 #define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: the round-2 Winograd kernel on v_mfma_f32_32x32x2_f32 (conv3x3_wino)        */
-#define W2XC_KERNEL_WINOGRAD4 5 /* mid layers with >= 64 output planes: Winograd F(4x4,3x3) (conv3x3_wino4), fp32 throughout: 2.25 multiplies per
-                                 * output instead of 4, interpolation points 0, +-3/4, +-3/2 (rounding error ~1.3x F(2x2)'s, every rtol 1e-4 gate
-                                 * holds).  What W2XC_KERNEL_AUTO picks; asked for explicitly it also runs on row-band views with the
-                                 * minimum halo, where its results depend on the banding at rounding level                            */
+#define W2XC_KERNEL_WINOGRAD4 5 /* mid layers with >= 64 output planes: Winograd F(4x4,3x3) (conv3x3_wino4) on planar activations, fp32
+                                 * throughout: 2.25 multiplies per output instead of 4, interpolation points 0, +-3/4, +-3/2 (error against the
+                                 * fp64 truth 1.6-1.9x the CPU oracle's own, 0.2-0.3 of the rtol 1e-4 gate on whole frames:
+                                 * tests/test_gpu_configs.py).  What W2XC_KERNEL_AUTO picks; asked for explicitly it also runs on row-band
+                                 * views with the minimum halo, where its results depend on the banding at rounding level          */
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */
@@ -86,13 +88,11 @@ typedef struct w2xc_opts {
                                * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
                                * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
     int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path (the one-plane last layer inside the epilogue
-                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  Results stay
-                               * inside the fp32 gate either way (tests/test_gpu_winograd.py).  The epilogue exists in
-                               * conv3x3_wino16: W2XC_FUSION_AUTO fuses where the layer before the last runs that kernel
-                               * (W2XC_KERNEL_WINOGRAD; environment W2XC_FUSE_LAST_FP32=0 turns it off) -- not under the
-                               * default conv3x3_wino4, whose frame is faster unfused; W2XC_FUSION_ON with
-                               * W2XC_KERNEL_AUTO runs that one layer on conv3x3_wino16 to fuse.
-                               * (The 16-bit modes: W2XC_SPLIT_FUSE_FIRST / _LAST.) */
+                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  Both Winograd
+                               * kernels carry the epilogue (conv3x3_wino4, the default, and conv3x3_wino16): W2XC_FUSION_AUTO = on,
+                               * W2XC_FUSION_OFF runs conv3x3_last as its own launch.  Results stay inside the fp32 gate either way
+                               * (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
+                               * (The 16-bit modes: environment W2XC_SPLIT_FUSE_FIRST / _LAST.) */
 } w2xc_opts;
 
 #define W2XC_FUSION_AUTO 0

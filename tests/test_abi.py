@@ -6,10 +6,8 @@ import ctypes as C
 import os
 import re
 
-# fp32 kernel of the 32- / 64- / 128-plane layers under W2XC_KERNEL_AUTO: the process default, read once from the environment
-# (w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32 / _WINOGRAD4 picks per call)
-MID_128 = ("conv3x3_mfma" if os.environ.get("W2XC_WINOGRAD", "1") == "0"
-           else {"32": "conv3x3_wino", "16": "conv3x3_wino16"}.get(os.environ.get("W2XC_WINO_KERNEL", "4"), "conv3x3_wino4"))
+# fp32 kernel of the 64- / 128-output-plane layers under W2XC_KERNEL_AUTO (w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32 / _WINOGRAD4 picks per call)
+MID_128 = "conv3x3_wino4"   # W2XC_KERNEL_AUTO = Winograd F(4x4,3x3) where it applies; no environment switches
 
 import numpy as np
 import pytest
@@ -192,7 +190,7 @@ def test_argument_validation(w2xc, noise1_layers):
     assert e.value.code == w2xc.ERR_PLANES
     assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first"
     # the one-plane last layer: inside conv3x3_wino4's / conv3x3_wino16's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
-    fused = MID_128 in ("conv3x3_wino4", "conv3x3_wino16") and os.environ.get("W2XC_FUSE_LAST_FP32", "1") != "0"
+    fused = True   # W2XC_FUSION_AUTO = on
     assert ms.kernel_name(6) == ("conv3x3_last_gather" if fused else "conv3x3_last")
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_last"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last_gather"

@@ -67,8 +67,7 @@ def test_kernel_choice_per_call(gpu):
     import os
     from tools import gen_model
     ms = gpu._ModelSet.from_layers(gen_model.synth_layers([1, 32, 64, 1], 5))
-    if os.environ.get("W2XC_WINOGRAD", "1") != "0":
-        assert ms.kernel_name(1) == ms.kernel_name(1, gpu.make_opts()) and ms.kernel_name(1).startswith("conv3x3_wino")
+    assert ms.kernel_name(1) == ms.kernel_name(1, gpu.make_opts()) == "conv3x3_wino4"   # W2XC_KERNEL_AUTO
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_MFMA)) == "conv3x3_mfma"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD32)) == "conv3x3_wino"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4)) == "conv3x3_wino4"

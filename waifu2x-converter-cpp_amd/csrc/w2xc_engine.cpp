@@ -425,18 +425,11 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2, MID_WINO4 = 3 };
 int mid_variant(const w2xc_opts &o)
 {
-    static const int env_default = [] {
-        const char *e = getenv("W2XC_WINOGRAD");
-        if (e && atoi(e) == 0) return (int)MID_MFMA;
-        const char *k = getenv("W2XC_WINO_KERNEL");
-        return (k && atoi(k) == 32) ? (int)MID_WINO32 : (k && atoi(k) == 16) ? (int)MID_WINO16 : (int)MID_WINO4;
-    }();
     switch (o.kernel) {
     case W2XC_KERNEL_MFMA: return MID_MFMA;
     case W2XC_KERNEL_WINOGRAD: return MID_WINO16;
     case W2XC_KERNEL_WINOGRAD32: return MID_WINO32;
-    case W2XC_KERNEL_WINOGRAD4: return MID_WINO4;
-    default: return env_default;
+    default: return MID_WINO4;   // W2XC_KERNEL_AUTO = W2XC_KERNEL_WINOGRAD4 (no environment switches: the choice is the caller's, per call)
     }
 }
 // the variant that really runs a (cin, cout) layer: conv3x3_wino16 needs two 32-plane groups (cout >= 64), the other Winograd kernel takes the rest
@@ -488,10 +481,9 @@ bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o)   // layout 
 // w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
 {
-    static const int env_default = [] { const char *e = getenv("W2XC_FUSE_LAST_FP32"); return (e && atoi(e) == 0) ? 0 : 1; }();
     const int n = (int)m->layers.size();
     if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || o.kernel == W2XC_KERNEL_DIRECT || n < 3) return false;
-    if (o.fusion == W2XC_FUSION_OFF || (o.fusion != W2XC_FUSION_ON && !env_default)) return false;
+    if (o.fusion == W2XC_FUSION_OFF) return false;   // (W2XC_FUSION_AUTO = on)
     const HostLayer &p = m->layers[n - 2], &q = m->layers[n - 1];
     if (q.nout != 1 || q.nin != p.nout || w2xc_pick_kernel(q.nin, 1) != W2XC_K_LAST || w2xc_pick_kernel(p.nin, p.nout) != W2XC_K_MFMA) return false;
     const int v = layer_mid_variant(m, n - 2, o);

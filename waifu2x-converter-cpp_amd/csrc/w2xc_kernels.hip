@@ -787,13 +787,6 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
 }
 
 // W2XC_MFMA_V2 (tuning aid): unset = default tilings, 1 = conv3x3_mfma2 with 4 waves everywhere, 3 = 8 waves where possible
-static int mfma_v2_enabled()
-{
-    static int v = -2;
-    if (v == -2) { const char *e = getenv("W2XC_MFMA_V2"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
 template <typename KernelT>
 static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -821,10 +814,8 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         const int key = d.cin * 1000 + d.cout;
         // Measured inside the 7-layer model (round 2, same box, same run): 8 waves (two per SIMD: the partner's MFMAs cover
         // this wave's non-MFMA issue slots) win wherever the output has >= 64 planes (32->64 -1.8 %, 64->64 -2.5 %,
-        // 64->128 -2.9 %, 128->128 -2.9 %); 32->32 has one plane block, so its 8 waves would split rows only
-        // (W2XC_MFMA_V2=3 forces 8 where the plane-block count divides, =1 forces 4).
-        const int v2 = mfma_v2_enabled();
-        const bool w8 = (v2 == 3) || (v2 != 1 && d.cout >= 64);
+        // 64->128 -2.9 %, 128->128 -2.9 %); 32->32 has one plane block, so its 8 waves would split rows only.
+        const bool w8 = d.cout >= 64;
         switch (key) {
         //                                  CIN  COUT  MB NB WM WN
         case 32032:  return launch_mfma2<32, 32, 2, 1, 4, 1>(d, stream);

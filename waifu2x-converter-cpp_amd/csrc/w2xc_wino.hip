@@ -345,11 +345,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// W2XC_WINO_MIN_CIN (tuning aid, default 32 = every mid shape): smallest plane count that takes this kernel
 bool w2xc_wino_supported(int cin, int cout)
 {
-    static const int min_cin = [] { const char *e = getenv("W2XC_WINO_MIN_CIN"); return e ? atoi(e) : 32; }();   // (thread-safe initialisation)
-    return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128) && cin >= min_cin && cout >= min_cin;
+    return (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128);
 }
 
 size_t w2xc_wino_packed_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
