@@ -12,28 +12,35 @@
 //   Work item  16 rows x 32 pixels of output (4 x 8 blocks of 4x4) x 64 output planes.  8 waves: wave (bt, pt) owns block tile bt
 //              (block rows 2 bt, 2 bt + 1) x plane tile pt (16 planes) x all 36 xi = 144 accumulators.
 //   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave, both operands from LDS in fragment order
-//              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand; A = U, lane = 16 k + o; B = V, lane = 16 k + t).
-//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS -- in TWO PHASES over two stages,
-//              so that every SIMD carries half a transform in every stage (a whole transform in one stage left the transforming wave
-//              alone on its SIMD for half of it: 4400-cycle stages where the MFMAs need 2304, round 3):
-//                phase A (stage g, for stage g + 2): 6 x (ds_read_b128 + ds_read_b64) of the raw tile, B^T d down the columns (84 VALU),
-//                         the 36 intermediate values PARKED in the V slot of stage g + 2 at the lane's own nine quads (lane-private);
-//                phase B (stage g + 1): the nine quads back, (.) B along the rows (84 VALU), the final V to the same addresses.
-//              Wave (bt, pt) transforms block tile bt for the stages g' = pt + 2 bt (mod 4): in every stage the four transforming waves
-//              (two in phase A, two in phase B) sit on four different SIMDs.  Nothing of a transform lives in registers across a stage
-//              boundary or an epilogue.  V is a ring of three slots (read g | final g + 1 | parked g + 2).
+//              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand, read two groups of four MFMAs ahead; A = U, lane = 16 k + o;
+//              B = V, lane = 16 k + t).  The stage's closing wait + barrier sit in FRONT of its last four MFMAs: behind the barrier a wave reads the
+//              first operands of the next stage and still has four MFMAs to issue while they arrive.
+//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS, in FOUR QUARTERS: every wave carries
+//              the same 42 VALU instructions in every stage (wave kind = its plane tile):
+//                kind 0 / 1 (for stage g + 2): rows 0..2 / 3..5 of the raw patch (3 x (ds_read_b128 + ds_read_b64)), the row pass d B, the 18
+//                           results PARKED in the V slot of stage g + 2;
+//                kind 2 / 3 (for stage g + 1): columns 0..2 / 3..5: the 18 parked values back, the column pass B^T (.), the final V to the same
+//                           addresses (position (i, j) sits at xi = 3 i + j | 18 + 3 i + j - 3: the column halves are two xi ranges, lane-private).
+//              Nothing of a transform lives in registers across a stage boundary or an epilogue.  V is a ring of three slots
+//              (read g | final g + 1 | parked g + 2).
 //   LDS        raw[3] x 11 KiB: the 18 x 36 pixel halo tile of a 4-channel slice as 16-byte chunks (channel kk, row R, pixel quad q) at
-//              chunk index kk * 168 + R * 9 + q -- the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free;
+//              chunk index kk * 168 + R * 9 + q (the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free);
 //              U[2] x 36 KiB + V[3] x 18 KiB + bias = 159.5 KiB.
 //   Transfers  LDS-DMA (global_load_lds_dwordx4), SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead) and 11 raw
-//              pieces (four stages ahead: phase A of stage g + 2 reads them, the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four consecutive pixels of one
-//              plane row: whole 128-byte lines from HBM, where the NHWC tile of round 3 pulled a 128-byte line per 32 bytes used.
+//              pieces (four stages ahead; the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four
+//              consecutive pixels of one plane row: whole 128-byte lines (the engine gives planar rows a stride of roundup32(w) floats).
+//   32 planes in  (IN_NHWC) the producers conv3x3_first / conv3x3_wino write NHWC pixels of one 128-byte line: a raw chunk is then the four
+//              channels of ONE pixel, the pixels of a row grouped by column mod 4 (conflict-free ds_read_b32 of a lane's channel).
 //   Epilogue   Y = A^T M A per output-row pair, bias, LeakyReLU; planar out: one 16-byte store = four pixels of a plane row, 8 lanes = one
-//              128-byte line (NHWC out, for a consumer that wants it: one store = a pixel's four planes).
-//   Edges      rows are clamped (replicate) in the transfer addresses; patch columns >= in_w are ZEROED in phase A (they only reach
+//              128-byte line (NHWC out for a consumer that wants it).  FUSE7: the model's one-plane LAST layer on the activations just
+//              computed ("taps as rows" on the MFMA), the four plane tiles of a block summed through the idle V slot: 9 partial tap planes
+//              per 64-plane block leave the chip (72 B per pixel instead of 512), conv3x3_last_gather finishes.
+//   Edges      rows are clamped (replicate) in the transfer addresses; patch columns >= in_w are ZEROED in the row pass (they only reach
 //              outputs >= out_w, and what is in memory there is not defined): results do not depend on memory contents outside the plane.
 //   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4); run_rows' four-rows-per-layer
 //              band geometry makes every region edge that is not a plane edge a block edge: bit-identical results across bandings.
+// Measured (round 4, 2160x3840, one MI355X): 128 -> 128 6.7-6.95 ms (round 3's NHWC kernel: 7.5 on the same box), frame 14.9 ms (16.4).  What is left
+// (s_memtime / ablations): the LDS-side work of the transform (parking doubles V's writes) and the transfers' issue cost, ~1 ms each of the 6.9.
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
@@ -50,18 +57,6 @@ __device__ unsigned long long w4_stamps[2][8192];
 #define W4_STAMP(idx) do { const int i_ = (idx); if (blockIdx.x == 0 && pt == 0 && lane == 0 && i_ < 8192) w4_stamps[bt][i_] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define W4_STAMP(idx) do { } while (0)
-#endif
-#ifndef W4P_NOP
-#define W4P_NOP -1   // experiment: s_nop W4P_NOP behind every MFMA (-1 = none); W4P_NOP2 = 1: a second one
-#endif
-#ifndef W4P_NOP2
-#define W4P_NOP2 0
-#endif
-#ifndef W4P_SVC
-#define W4P_SVC 0    // where a stage's non-MFMA work sits: 0 = spread over the first MFMA slots | 1 = one block in front of the first MFMA | 2 = one block,
-#endif               // in front of the first MFMA in the waves of block tile 1, behind MFMA 31 in those of block tile 0 (the two waves of a SIMD in opposite phases)
-#ifndef W4P_CLOSE_AT
-#define W4P_CLOSE_AT 32   // MFMA slot in front of which a stage's closing wait + barrier sit (a multiple of 4 >= 28; 32 = in front of the last group)
 #endif
 #ifndef W4P_T0
 #define W4P_T0 3     // MFMA slot of a stage behind which a wave's transform arithmetic starts (its LDS reads sit behind slot 0)
@@ -85,24 +80,6 @@ static __device__ __forceinline__ void bt6(float &x0, float &x1, float &x2, floa
     x3 = u + v;
     x4 = u - v;
     x5 = y5;
-}
-
-// the same in two halves (8 + 6 operations) with p, q, u, v carried in t[0..3]: a stage spreads them over two groups of MFMAs
-static __device__ __forceinline__ void bt6a(float &x0, float x1, float x2, float x3, float x4, float (&t)[4])
-{
-    x0 = __builtin_fmaf(-2.8125f, x2, __builtin_fmaf(1.265625f, x0, x4));
-    t[0] = __builtin_fmaf(-2.25f, x2, x4);
-    t[1] = __builtin_fmaf(-1.6875f, x1, 0.75f * x3);
-    t[2] = __builtin_fmaf(-0.5625f, x2, x4);
-    t[3] = __builtin_fmaf(-0.84375f, x1, 1.5f * x3);
-}
-static __device__ __forceinline__ void bt6b(float &x1, float &x2, float &x3, float &x4, float &x5, const float (&t)[4])
-{
-    x5 = __builtin_fmaf(-2.8125f, x3, __builtin_fmaf(1.265625f, x1, x5));
-    x1 = t[0] + t[1];
-    x2 = t[0] - t[1];
-    x3 = t[2] + t[3];
-    x4 = t[2] - t[3];
 }
 
 // y = A^T m for a 6-vector (12 fma / mul / add)
@@ -340,14 +317,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         constexpr int g = decltype(G_)::value;
         if constexpr (!(W4_ABL & 3)) bt6(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5]);
     };
-    float tq[4];
-    auto pass6h = [&](auto H_) {                                   // half-pass H = 2 g + {0, 1} of row / column g
-        constexpr int hh = decltype(H_)::value, g = hh >> 1;
-        if constexpr (!(W4_ABL & 3)) {
-            if constexpr ((hh & 1) == 0) bt6a(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], tq);
-            else bt6b(dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5], tq);
-        }
-    };
     using CT = std::true_type;
     using CF = std::false_type;
     // the quads a quarter touches: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
@@ -359,10 +328,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         });
     };
 
-    auto run = [&](auto KIND_, auto BT_) {
+    auto run = [&](auto KIND_) {
     constexpr int KIND = decltype(KIND_)::value;
-    constexpr int BT = decltype(BT_)::value;   // (only W4P_SVC = 2 distinguishes the two block tiles at compile time)
-    (void)BT;
     using CK = std::integral_constant<int, KIND>;
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -459,47 +426,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             };
             auto tr_mask = [&]() { if constexpr (KIND < 2) raw_mask(xlimA); };
             auto tr_writes = [&](auto F_, auto L_) { quads_io(CK{}, CT{}, KIND < 2 ? slotA : slotB, F_, L_); };
-            // W4P_SVC = 1 / 2: everything of a stage that is not an MFMA or an operand read as ONE block -- transform reads, the seven transfers (while the
-            // reads fly), the 42 VALU instructions, the writes.  The two waves of a SIMD run their MFMAs one after the other (the older wave wins every
-            // arbitration: s_memtime shows 1300 cycles for its 36 MFMAs, then 1130 more for the younger one's), so an instruction between two MFMAs
-            // of a wave costs what it costs a wave alone on the SIMD (VALU 11, LDS 22-26 cycles of matrix-pipe time): as a block it costs its issue time.
-            auto service = [&]() {
-                tr_reads();
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(W4_ABL & 16)) {
-                    static_for<0, 4>([&](auto Q) { dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, Q); });
-                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
-                }
-                if constexpr (!(W4_ABL & 32)) {
-                    dma_raw(C0{}, r1, r_slice);
-                    if (wave < 3) dma_raw(C1{}, r1, r_slice);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                tr_mask();
-                static_for<0, 3>([&](auto G) { pass6(G); });
-                __builtin_amdgcn_sched_barrier(0);
-                tr_writes(C0{}, C6{});
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            // W4P_SVC = 3: the work spread EVENLY, one portion behind the fourth MFMA of every group of four -- the two waves of a SIMD then fall into
-            // opposite phases by themselves (the older wave wins every arbitration for the matrix pipe, so the younger one issues its MFMAs while
-            // the older one is in a portion, and its own portions while the older one multiplies)
-            auto portion = [&](auto G_) {
-                constexpr int g = decltype(G_)::value;
-                if constexpr (g < 4 && !(W4_ABL & 16)) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, G_);
-                if constexpr (g == 4 && !(W4_ABL & 16)) { if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, G_); }
-                if constexpr (g == 5 && !(W4_ABL & 32)) dma_raw(C0{}, r1, r_slice);
-                if constexpr (g == 6 && !(W4_ABL & 32)) { if (wave < 3) dma_raw(C1{}, r1, r_slice); }
-                if constexpr (g == 0) tr_mask();
-                if constexpr (g < 6) pass6h(G_);
-                if constexpr (g == 6) tr_writes(C0{}, C6{});
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            constexpr int SVC_XI = W4P_SVC == 1 ? 0 : (W4P_SVC == 2 ? (BT == 0 ? 32 : 0) : -1);
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
-                if constexpr (xi == SVC_XI) service();
-                if constexpr (xi == W4P_CLOSE_AT) {
+                if constexpr (xi == 32) {
                     // ---- the stage's close, in front of its last four MFMAs ----
                     W4_STAMP(stamp++);
                     // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
@@ -523,18 +452,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) % (PF + 1)][xi & 3], b4[(xi >> 2) % (PF + 1)][xi & 3], acc[xi], 0, 0, 0);
-                if constexpr (W4P_NOP >= 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
-                if constexpr (W4P_NOP2 != 0) asm volatile("s_nop %0" ::"n"(W4P_NOP >= 0 ? W4P_NOP : 0));
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (W4P_SVC == 3) {
-                    if constexpr (xi == 0) {
-                        tr_reads();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr ((xi & 3) == 3 && xi < 28) portion(std::integral_constant<int, (xi >> 2)>{});
-                }
-                // the stage's other work (W4P_SVC = 0: spread over the first MFMA slots)
-                if constexpr (W4P_SVC == 0) {
+                // the stage's other work, behind the first MFMA slots: transfers (U pieces first, the raw pieces last: the closing wait leaves them in
+                // flight), then this wave's quarter of the input transform
+                {
                     if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
                         dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
                         __builtin_amdgcn_sched_barrier(0);
@@ -707,25 +628,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
     };
-#if W4P_SVC == 2
-    switch (wave) {
-    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
-    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
-    case 3: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
-    case 4: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
-    case 5: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
-    case 6: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
-    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}); break;
-    }
-#else
     switch (pt) {
-    case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
-    case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
-    default: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
