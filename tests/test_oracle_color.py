@@ -74,6 +74,34 @@ def test_cubic(oracle_built, h, w):
     assert np.array_equal(orc.resize2x_nearest(x), np.repeat(np.repeat(x, 2, 0), 2, 1))
 
 
+def _keys_matrix(n, a=-0.75):
+    """(2n x n) fp64 matrix of a 2x cubic-convolution upscale along one axis: destination d samples the source at (d + 0.5) / 2 - 0.5 with Keys'
+    kernel (a = -0.75, OpenCV's INTER_CUBIC) on the four taps floor(s) - 1 .. floor(s) + 2, tap indices CLAMPED to the plane (BORDER_REPLICATE)"""
+    def k(t):
+        t = abs(t)
+        return (a + 2) * t ** 3 - (a + 3) * t ** 2 + 1 if t <= 1 else a * t ** 3 - 5 * a * t ** 2 + 8 * a * t - 4 * a if t < 2 else 0.0
+    m = np.zeros((2 * n, n))
+    for d in range(2 * n):
+        sx = (d + 0.5) / 2 - 0.5
+        f = int(np.floor(sx))
+        for tap in range(f - 1, f + 3):
+            m[d, min(max(tap, 0), n - 1)] += k(sx - tap)
+    return m
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (2, 2), (3, 5), (1, 7), (12, 9)])
+def test_cubic_border_rule_second_implementation(oracle_built, h, w):
+    """the border handling of resize(2x, INTER_CUBIC) (main.cpp:144) pinned a second time, on one- and two-pixel planes where EVERY tap is a clamped
+    one: a dense fp64 matrix form of Keys' cubic convolution (separable: M_h x M_w^T), written from the kernel's definition -- independent of the C
+    loops and of torch's implementation.  (OpenCV itself is absent: what stays unpinned is its fp32 evaluation ORDER, worth ~1e-7, see the C header.)"""
+    x = np.random.default_rng(100 * h + w).random((h, w), dtype=np.float32)
+    want = _keys_matrix(h) @ x.astype(np.float64) @ _keys_matrix(w).T
+    got = orc.resize2x_cubic(x)
+    assert got.shape == (2 * h, 2 * w) and np.abs(got - want).max() < 2e-6
+    if h == 1 and w == 1:
+        assert np.allclose(got, x[0, 0], atol=1e-6)   # one pixel: every tap clamps onto it, the weights sum to 1
+
+
 @pytest.mark.parametrize("sh,sw,dh,dw", [(40, 60, 30, 45), (64, 64, 40, 40), (50, 30, 30, 18), (17, 23, 34, 46), (8, 8, 5, 3), (1, 9, 1, 5)])
 def test_linear(oracle_built, sh, sw, dh, dw):
     """resize(INTER_LINEAR) -- the CLI's final shrink (main.cpp:158-167: ratios 0.75, 0.625, 0.6, ...) and an enlargement --

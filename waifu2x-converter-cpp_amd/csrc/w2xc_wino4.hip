@@ -239,7 +239,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     const int tr_r = lane >> 5, tr_k = (lane >> 3) & 3, tr_c = lane & 7;
     const unsigned tr_rd = IN_NHWC ? (unsigned)((4 * (2 * bt + tr_r) * 36 + tr_c) * 16 + tr_k * 4)                // + buffer + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16
                                    : (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);        // + buffer + i * 144 (+ 16)
-    const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);  // + slot * V_BYTES + (xi / 4) * 2048
+    // V-slot address of this lane's patch (+ slot * V_BYTES + (xi / 4) * 2048).  The row-pass waves (kinds 0 / 1) need the (r, kk, c) lane order above for
+    // their raw reads; the column-pass waves (2 / 3) touch only the V slot and take patch = lane: their b128 accesses are then lane-linear
+    // (conflict-free), where the (r, kk, c) order puts two lanes of every 16-lane access group on the same banks
+    const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (pt < 2 ? (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16) : (unsigned)lane * 16u);
 
     // The input transform V = B^T d B of a patch in FOUR QUARTERS, one per wave and stage (KIND = the wave's plane tile pt, fixed for the kernel):
     //   KIND 0 / 1  (for stage g + 2)  rows 0..2 / 3..5 of the raw patch: 3 x (ds_read_b128 + ds_read_b64), the row pass s[i][.] = d[i][.] B
