@@ -516,6 +516,8 @@ def main():
                               "algorithmic_tflops": round(alg_tf, 2) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
             if per_layer[-1]["kernel"] == "conv3x3_last_gather":
+                for kf in ("tflops", "frac_of_peak", "algorithmic_tflops", "algorithmic_GBs_fp32_nhwc"):
+                    per_layer[-1][kf] = None   # (this launch adds 9 x Cout/64 partial values per pixel: the layer's multiplies are in the previous launch)
                 per_layer[-1]["note"] = ("last layer fused: its MFMA work runs in the previous layer's epilogue (that layer's `ms` includes it, its FLOP "
                                          "figures do not); this launch only sums the partial tap planes")
         traffic, traffic_note = (pmc_traffic(ms.kernel_name(dom, opts), ms.planes(dom)[0], ms.planes(dom)[1], H, W, args.precision)
