@@ -15,19 +15,18 @@
 //              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand, read two groups of four MFMAs ahead; A = U, lane = 16 k + o;
 //              B = V, lane = 16 k + t).  The stage's closing wait + barrier sit in FRONT of its last four MFMAs: behind the barrier a wave reads the
 //              first operands of the next stage and still has four MFMAs to issue while they arrive.
-//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS, in FOUR QUARTERS: every wave carries
-//              the same 42 VALU instructions in every stage (wave kind = its plane tile):
-//                kind 0 / 1 (for stage g + 2): rows 0..2 / 3..5 of the raw patch (3 x (ds_read_b128 + ds_read_b64)), the row pass d B, the 18
-//                           results PARKED in the V slot of stage g + 2;
-//                kind 2 / 3 (for stage g + 1): columns 0..2 / 3..5: the 18 parked values back, the column pass B^T (.), the final V to the same
-//                           addresses (position (i, j) sits at xi = 3 i + j | 18 + 3 i + j - 3: the column halves are two xi ranges, lane-private).
-//              Nothing of a transform lives in registers across a stage boundary or an epilogue.  V is a ring of three slots
-//              (read g | final g + 1 | parked g + 2).
+//   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS.  ONE wave transforms a 4-channel slice of
+//              its block tile in FOUR QUARTERS over four consecutive stages, the 36 values in REGISTERS in between (Q0 raw patch + row pass of rows
+//              0..2 | Q1 rows 3..5 | Q2 column pass of columns 0..2 | Q3 columns 3..5 + nine ds_write_b128 of V): every wave carries the same 42 VALU
+//              instructions in every stage, the four waves of a block tile are one quarter apart, the two waves of a SIMD two.  The pipeline runs
+//              across items; the waves in mid-transform at an item's end park their 36 values in LDS across the epilogue.  V is two slots.
+//              The MFMAs are asm with the accumulator TIED: as builtins the allocator gave three of four a destination other than their
+//              accumulator input, the accumulators migrated through the file and some were spilled inside the stages.
 //   LDS        raw[3] x 11 KiB: the 18 x 36 pixel halo tile of a 4-channel slice as 16-byte chunks (channel kk, row R, pixel quad q) at
 //              chunk index kk * 168 + R * 9 + q (the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free);
-//              U[2] x 36 KiB + V[3] x 18 KiB + bias = 159.5 KiB.
+//              U[2] x 36 KiB + V[2] x 18 KiB + 18 KiB (with U slot 1 the parking area of an epilogue) + bias = 159.5 KiB.
 //   Transfers  LDS-DMA (global_load_lds_dwordx4), SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead) and 11 raw
-//              pieces (four stages ahead; the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four
+//              pieces (the slice Q0 reads two stages later; the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four
 //              consecutive pixels of one plane row: whole 128-byte lines (the engine gives planar rows a stride of roundup32(w) floats).
 //   32 planes in  (IN_NHWC) the producers conv3x3_first / conv3x3_wino write NHWC pixels of one 128-byte line: a raw chunk is then the four
 //              channels of ONE pixel, the pixels of a row grouped by column mod 4 (conflict-free ds_read_b32 of a lane's channel).
@@ -39,8 +38,9 @@
 //              outputs >= out_w, and what is in memory there is not defined): results do not depend on memory contents outside the plane.
 //   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4); run_rows' four-rows-per-layer
 //              band geometry makes every region edge that is not a plane edge a block edge: bit-identical results across bandings.
-// Measured (round 4, 2160x3840, one MI355X): 128 -> 128 6.7-6.95 ms (round 3's NHWC kernel: 7.5 on the same box), frame 14.9 ms (16.4).  What is left
-// (s_memtime / ablations): the LDS-side work of the transform (parking doubles V's writes) and the transfers' issue cost, ~1 ms each of the 6.9.
+// Measured (round 4, 2160x3840, one MI355X): 128 -> 128 6.5-6.8 ms (round 3's NHWC kernel: 7.5 on the same box), frame 14.4 ms (16.4).  s_memtime: a stage
+// takes ~3350 cycles (2304 = the matrix pipe's time for the 72 MFMAs of a SIMD), an item's first stage + epilogue another ~9.5k of its 117k
+// (profiles/r4_sweeps.log).
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
@@ -60,6 +60,9 @@ __device__ unsigned long long w4_stamps[2][8192];
 #endif
 #ifndef W4P_T0
 #define W4P_T0 3     // MFMA slot of a stage behind which a wave's transform arithmetic starts (its LDS reads sit behind slot 0)
+#endif
+#ifndef W4_PF
+#define W4_PF 2      // operand look-ahead in groups of four MFMAs (1: two register buffers, 2: three)
 #endif
 #ifndef W4_ABL
 #define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores | 128 no operand reads inside the stages
@@ -96,28 +99,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // position (i, j) of the transformed domain in the fragment order: the column halves j < 3 / j >= 3 as the xi ranges [0, 18) / [18, 36)
 static constexpr __host__ __device__ int xi_of(int i, int j) { return j < 3 ? 3 * i + j : 18 + 3 * i + (j - 3); }
-// index in a quarter's 18 registers of the value at xi, -1 if the quarter does not own it.  KIND 0 / 1 (row pass of raw rows 3 h .. 3 h + 2):
-// dd[6 r + j] = row 3 h + r, column j.  KIND 2 / 3 (column pass of columns 3 h .. 3 h + 2): dd[6 jj + i] = row i of column 3 h + jj.
-static constexpr __host__ __device__ int w4p_own(int kind, int xi)
-{
-    const int h = kind & 1, half = xi / 18, rem = xi % 18, i = rem / 3, jj = rem % 3;
-    if (kind < 2) return i / 3 == h ? (i - 3 * h) * 6 + 3 * half + jj : -1;
-    return half == h ? jj * 6 + i : -1;
-}
-// the n-th quad (four consecutive xi) a quarter touches, -1 past the end: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
-static constexpr __host__ __device__ int w4p_quad(int kind, int n)
-{
-    int seen = 0;
-    for (int q = 0; q < 9; q++) {
-        bool any = false;
-        for (int e = 0; e < 4; e++) any = any || w4p_own(kind, 4 * q + e) >= 0;
-        if (any) {
-            if (seen == n) return q;
-            seen++;
-        }
-    }
-    return -1;
-}
+// register (dd[6 i + j]) of the value at position xi of the fragment order
+static constexpr __host__ __device__ int w4p_dd_of(int xi) { return 6 * ((xi % 18) / 3) + 3 * (xi / 18) + (xi % 18) % 3; }
 
 }   // namespace
 
@@ -132,7 +115,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     constexpr unsigned RAW_BYTES = RAW_PIECES * 1024;
     constexpr unsigned U_BASE = 3 * RAW_BYTES, U_BYTES = 36 * 1024;
     constexpr unsigned V_BASE = U_BASE + 2 * U_BYTES, V_BYTES = 18 * 1024;
-    constexpr unsigned BIAS_BASE = V_BASE + 3 * V_BYTES;
+    constexpr unsigned SPARE_BASE = V_BASE + 2 * V_BYTES;   // 18 KiB: with U slot 1 the parking area across an epilogue
+    constexpr unsigned BIAS_BASE = SPARE_BASE + V_BYTES;
     static_assert(CIN % 16 == 0 && COUT % 64 == 0 && NST % 4 == 0 && NST >= 8, "planes");
     constexpr int STRIP = 16;
     const int tiles_y = nitems / (NOB * tiles_x);
@@ -153,7 +137,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pt = wave & 3, bt = wave >> 2;
-    const int t = lane & 15, k = lane >> 4;
+    // ONE lane-linear VGPR lives through the kernel (lane * 16); everything else that depends on the lane is derived from an opaque copy of it where it is
+    // used -- hoisted out of the item loop, the ~30 lane-derived values of the epilogue, the transfers and the transform overflow the 256 registers
+    // into scratch, and a scratch reload inside a stage waits with vmcnt(0) for every transfer in flight
+    const unsigned b_voff = (unsigned)lane * 16u;
+    auto lin = [&]() { unsigned v = b_voff; asm volatile("" : "+v"(v)); return v; };
+    auto lane_o = [&]() { return (int)(lin() >> 4); };
 
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const int cq = nitems >> 3, cr = nitems & 7;
@@ -174,6 +163,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     auto tile_offsets = [&](int it) {
         int ty_, tx_;
         tile_coords(it / NOB, ty_, tx_);
+        const int lane_t = lane_o();   // (nothing of this hoisted out of the item loop)
         const int y0 = ty_ * ROWS - d.wino_py + d.off_y, x0 = tx_ * 32 + d.off_x;
         const int yb = clampi(y0, 0, d.in_h - 1);
         a_base = reinterpret_cast<const char *>(d.in) + (long long)yb * rs4;
@@ -185,7 +175,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             xlim_r = 64;   // (nothing to mask)
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
-                int ci = (jj * 8 + wave) * 64 + lane;
+                int ci = (jj * 8 + wave) * 64 + lane_t;
                 ci = ci < (ROWS + 2) * 36 ? ci : (ROWS + 2) * 36 - 1;
                 const int R = ci / 36, slot = ci - R * 36;
                 const int x = 4 * (slot % 9) + slot / 9;
@@ -198,7 +188,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         const int xq_last = (d.in_w - 1) & ~3;
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
-            const int ci = (jj * 8 + wave) * 64 + lane;
+            const int ci = (jj * 8 + wave) * 64 + lane_t;
             int kk = ci / CHS;
             kk = kk < 4 ? kk : 3;
             const int rem = ci - kk * CHS;
@@ -221,7 +211,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         lds_dma16_si<jj * 8192u>(sbase, voff[jj], wbase + roff);
     };
     // U of (64-plane block ob, stage s_): 36 pieces of 1 KiB (one per xi); wave w sends xi = w, w + 8, w + 16, w + 24 and (w < 4) 32 + w
-    const unsigned b_voff = (unsigned)lane * 16u;
     const char *wpk_w = reinterpret_cast<const char *>(d.wpk) + (size_t)wave * 1024;
     auto dma_u = [&](int ob, int s_, auto SLOT, auto Q) {     // piece xi = 8 q + wave
         constexpr unsigned slot = decltype(SLOT)::value;
@@ -231,128 +220,123 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     };
 
     // ---- addressing ----
-    // MFMA operands: lane-linear dwords
-    const unsigned ua0 = U_BASE + (unsigned)pt * 1024u + (unsigned)lane * 16u;    // + slot * U_BYTES + (xi / 4) * 4096: four xi per b128
-    const unsigned va0 = V_BASE + (unsigned)bt * 1024u + (unsigned)lane * 16u;    // + slot * V_BYTES + (xi / 4) * 2048
+    // MFMA operands: lane-linear 16-byte quads, (wave-uniform base) + lane * 16: A = U at U_BASE + slot * U_BYTES + pt * 1024 + (xi / 4) * 4096,
+    // B = V at V_BASE + slot * V_BYTES + bt * 1024 + (xi / 4) * 2048.  ONE lane-linear VGPR (b_voff) + SGPR bases: the copies the compiler would
+    // otherwise keep per base cost registers this kernel does not have.
+    const unsigned ua_u = U_BASE + (unsigned)pt * 1024u, va_u = V_BASE + (unsigned)bt * 1024u;
     // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch row i, columns 0..3 = chunk (kk, 4 (2 bt + r) + i, c),
     // columns 4, 5 = the first half of chunk (kk, same row, c + 1)
-    const int tr_r = lane >> 5, tr_k = (lane >> 3) & 3, tr_c = lane & 7;
-    const unsigned tr_rd = IN_NHWC ? (unsigned)((4 * (2 * bt + tr_r) * 36 + tr_c) * 16 + tr_k * 4)                // + buffer + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16
-                                   : (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);        // + buffer + i * 144 (+ 16)
-    // V-slot address of this lane's patch (+ slot * V_BYTES + (xi / 4) * 2048).  The row-pass waves (kinds 0 / 1) need the (r, kk, c) lane order above for
-    // their raw reads; the column-pass waves (2 / 3) touch only the V slot and take patch = lane: their b128 accesses are then lane-linear
-    // (conflict-free), where the (r, kk, c) order puts two lanes of every 16-lane access group on the same banks
-    const unsigned tr_wr = V_BASE + (unsigned)bt * 1024u + (pt < 2 ? (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16) : (unsigned)lane * 16u);
-
-    // The input transform V = B^T d B of a patch in FOUR QUARTERS, one per wave and stage (KIND = the wave's plane tile pt, fixed for the kernel):
-    //   KIND 0 / 1  (for stage g + 2)  rows 0..2 / 3..5 of the raw patch: 3 x (ds_read_b128 + ds_read_b64), the row pass s[i][.] = d[i][.] B
-    //               (3 x 14 fma / add), the 18 results parked in the V slot of stage g + 2;
-    //   KIND 2 / 3  (for stage g + 1)  columns 0..2 / 3..5: the 18 parked values s[.][j] back, the column pass V[.][j] = B^T s[.][j] (3 x 14),
-    //               the 18 final values to the same addresses.
-    // Position (i, j) of the transformed domain sits at xi = xi_of(i, j) = 3 i + j (j < 3), 18 + 3 i + j - 3 (j >= 3) of the fragment order
-    // (the weight image and the epilogue use the same map): the column halves are the xi ranges [0, 18) and [18, 36), so a KIND 2 / 3 lane
-    // reads and rewrites only its own half (lane-private addresses, nothing of another wave's quarter).  Every wave carries the same 42 VALU
-    // instructions in every stage -- in round 3 and in the first version of this kernel one wave of a SIMD carried a whole (then half a) transform
-    // while its partner carried none, finished its MFMAs early, and left the transforming wave alone on the SIMD where a VALU instruction
-    // between MFMAs costs 11 cycles instead of 2 (3300-cycle stages against 2304 of MFMA time, s_memtime).
-    float dd[18];
-    // the 18 values a quarter owns, by xi: KIND 0 / 1 own rows 3 h .. 3 h + 2 (both column halves), KIND 2 / 3 own [18 h, 18 h + 18); dd index of xi:
-    // move the owned values of quad q (xi = 4 q .. 4 q + 3) between dd and LDS with the widest aligned accesses
-    auto quad_io = [&](auto KIND_, auto Q_, auto WR_, char *p) {
-        constexpr int kind = decltype(KIND_)::value, q = decltype(Q_)::value;
-        constexpr bool wr = decltype(WR_)::value;
-        constexpr int i0 = w4p_own(kind, 4 * q), i1 = w4p_own(kind, 4 * q + 1), i2 = w4p_own(kind, 4 * q + 2), i3 = w4p_own(kind, 4 * q + 3);
-        char *a = p + q * 2048;
-        if constexpr ((W4_ABL & 2) != 0) {
-            if constexpr (!wr) {
-                if constexpr (i0 >= 0) dd[i0] = 1.0f;
-                if constexpr (i1 >= 0) dd[i1] = 2.0f;
-                if constexpr (i2 >= 0) dd[i2] = 3.0f;
-                if constexpr (i3 >= 0) dd[i3] = 4.0f;
-            }
-        } else if constexpr (i0 >= 0 && i1 >= 0 && i2 >= 0 && i3 >= 0) {
-            if constexpr (wr) *reinterpret_cast<f32x4 *>(a) = f32x4{dd[i0], dd[i1], dd[i2], dd[i3]};
-            else { const f32x4 v = *reinterpret_cast<const f32x4 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; dd[i2] = v[2]; dd[i3] = v[3]; }
-        } else {
-            if constexpr (i0 >= 0 && i1 >= 0) {
-                if constexpr (wr) *reinterpret_cast<f32x2 *>(a) = f32x2{dd[i0], dd[i1]};
-                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a); dd[i0] = v[0]; dd[i1] = v[1]; }
-            } else {
-                if constexpr (i0 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a) = dd[i0]; else dd[i0] = *reinterpret_cast<const float *>(a); }
-                if constexpr (i1 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 4) = dd[i1]; else dd[i1] = *reinterpret_cast<const float *>(a + 4); }
-            }
-            if constexpr (i2 >= 0 && i3 >= 0) {
-                if constexpr (wr) *reinterpret_cast<f32x2 *>(a + 8) = f32x2{dd[i2], dd[i3]};
-                else { const f32x2 v = *reinterpret_cast<const f32x2 *>(a + 8); dd[i2] = v[0]; dd[i3] = v[1]; }
-            } else {
-                if constexpr (i2 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 8) = dd[i2]; else dd[i2] = *reinterpret_cast<const float *>(a + 8); }
-                if constexpr (i3 >= 0) { if constexpr (wr) *reinterpret_cast<float *>(a + 12) = dd[i3]; else dd[i3] = *reinterpret_cast<const float *>(a + 12); }
-            }
-        }
+    auto tr_rd = [&]() {
+        const int l = lane_o(), tr_r = l >> 5, tr_k = (l >> 3) & 3, tr_c = l & 7;
+        return IN_NHWC ? (unsigned)((4 * (2 * bt + tr_r) * 36 + tr_c) * 16 + tr_k * 4)                // + buffer + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16
+                       : (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);        // + buffer + i * 144 (+ 16)
     };
-    // KIND 0 / 1: raw row 3 h + r of the patch into dd[6 r .. 6 r + 5]
-    auto raw_read = [&](auto KIND_, auto R_, const char *src) {
-        constexpr int h = decltype(KIND_)::value & 1, r = decltype(R_)::value, i = 3 * h + r;
+    // V-slot address of this lane's patch in the fragment order lane = 16 kk + block (+ slot * V_BYTES + (xi / 4) * 2048)
+    auto tr_wr = [&]() {
+        const int l = lane_o(), tr_r = l >> 5, tr_k = (l >> 3) & 3, tr_c = l & 7;
+        return V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);
+    };
+
+    // The input transform V = B^T d B of a patch set (16 blocks x 4 channels = one patch per lane) by ONE wave in FOUR QUARTERS over four consecutive
+    // stages, the 36 values in REGISTERS in between:
+    //   Q0 (stage n - 4)  the raw patch (6 x (ds_read_b128 + ds_read_b64)), columns outside the plane zeroed, the row pass d B of rows 0..2 (3 x 14 fma / add)
+    //   Q1 (stage n - 3)  the row pass of rows 3..5
+    //   Q2 (stage n - 2)  the column pass B^T (.) of columns 0..2
+    //   Q3 (stage n - 1)  the column pass of columns 3..5, V of stage n as nine ds_write_b128 into the slot stage n - 2 has read
+    // With PH = (pt - 2 bt) mod 4 a wave runs quarter (stage - PH) mod 4: it transforms the slices n = PH (mod 4) of its block tile, every wave carries
+    // the same 42 VALU instructions in every stage, and the two waves of a SIMD (same pt) are two quarters apart (raw reads beside pure arithmetic).
+    // The pipeline runs ACROSS items (the last four stages of an item work on the first slices of the next): the three waves of a block tile that
+    // are in mid-transform at an item's end park their 36 values in LDS across the epilogue (whose registers are full) -- in the U slot and the 18 KiB
+    // that are idle then -- and take them back behind it.  Nothing else of a transform touches LDS between its raw reads and its V writes: round 4's
+    // earlier forms parked the intermediates of EVERY transform in the V ring (row-pass waves -> column-pass waves), and that traffic alone cost 0.7
+    // of layer 6's 6.7 ms (timing-only ablation, profiles/r4_sweeps.log 8).
+    float dd[36];
+    auto raw_read = [&](const char *src, auto I_) {          // patch row i
+        constexpr int i = decltype(I_)::value;
         if constexpr ((W4_ABL & 2) != 0) {
-            static_for<0, 6>([&](auto JJ) { dd[r * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
+            static_for<0, 6>([&](auto JJ) { dd[i * 6 + decltype(JJ)::value] = (float)(i + decltype(JJ)::value); });
         } else if constexpr (IN_NHWC) {
             static_for<0, 6>([&](auto JJ) {
                 constexpr int j = decltype(JJ)::value;
-                dd[r * 6 + j] = *reinterpret_cast<const float *>(src + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16);
+                dd[i * 6 + j] = *reinterpret_cast<const float *>(src + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16);
             });
         } else {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(src + i * 144);
             const f32x2 b = *reinterpret_cast<const f32x2 *>(src + i * 144 + 16);
-            dd[r * 6 + 0] = a[0]; dd[r * 6 + 1] = a[1]; dd[r * 6 + 2] = a[2]; dd[r * 6 + 3] = a[3];
-            dd[r * 6 + 4] = b[0]; dd[r * 6 + 5] = b[1];
+            dd[i * 6 + 0] = a[0]; dd[i * 6 + 1] = a[1]; dd[i * 6 + 2] = a[2]; dd[i * 6 + 3] = a[3];
+            dd[i * 6 + 4] = b[0]; dd[i * 6 + 5] = b[1];
         }
     };
-    auto raw_mask = [&](int xlim) {                               // patch columns outside the plane: zero (wave-uniform test first)
+    auto raw_mask = [&](int xlim) {                           // patch columns outside the plane: zero (wave-uniform test first)
         if (xlim < 34) {
-            const int lim = xlim - 4 * tr_c;
-            static_for<0, 18>([&](auto E) {
+            const int lim = xlim - 4 * (lane_o() & 7);
+            static_for<0, 36>([&](auto E) {
                 constexpr int e = decltype(E)::value;
                 dd[e] = (e % 6) < lim ? dd[e] : 0.0f;
             });
         }
     };
-    auto pass6 = [&](auto G_) {                                    // bt6 over dd[6 g .. 6 g + 5]: a raw row (KIND 0 / 1) or a column of s (KIND 2 / 3)
-        constexpr int g = decltype(G_)::value;
-        if constexpr (!(W4_ABL & 3)) bt6(dd[g * 6 + 0], dd[g * 6 + 1], dd[g * 6 + 2], dd[g * 6 + 3], dd[g * 6 + 4], dd[g * 6 + 5]);
+    // (the pins keep a pass in the stage it was written in: without them the compiler sinks it into the stage that consumes its results)
+    auto row_pass = [&](auto I_) {                            // s[i][.] = d[i][.] B
+        constexpr int i = decltype(I_)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
+        asm volatile("" : "+v"(dd[i * 6 + 0]), "+v"(dd[i * 6 + 1]), "+v"(dd[i * 6 + 2]), "+v"(dd[i * 6 + 3]), "+v"(dd[i * 6 + 4]), "+v"(dd[i * 6 + 5]));
     };
-    using CT = std::true_type;
-    using CF = std::false_type;
-    // the quads a quarter touches: KIND 0: 0 1 2 4 5 6 | 1: 2 3 4 6 7 8 | 2: 0 1 2 3 4 | 3: 4 5 6 7 8
-    auto quads_io = [&](auto KIND_, auto WR_, char *p, auto FIRST_, auto LAST_) {   // quads [FIRST, LAST) of the kind's list
-        constexpr int kind = decltype(KIND_)::value, first = decltype(FIRST_)::value, last = decltype(LAST_)::value;
-        static_for<first, last>([&](auto N_) {
-            constexpr int q = w4p_quad(kind, decltype(N_)::value);
-            if constexpr (q >= 0) quad_io(KIND_, std::integral_constant<int, q>{}, WR_, p);
-        });
+    auto col_pass = [&](auto J_) {                            // V[.][j] = B^T s[.][j]
+        constexpr int j = decltype(J_)::value;
+        if constexpr (!(W4_ABL & 3)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
+        asm volatile("" : "+v"(dd[0 * 6 + j]), "+v"(dd[1 * 6 + j]), "+v"(dd[2 * 6 + j]), "+v"(dd[3 * 6 + j]), "+v"(dd[4 * 6 + j]), "+v"(dd[5 * 6 + j]));
     };
-
-    auto run = [&](auto KIND_) {
-    constexpr int KIND = decltype(KIND_)::value;
-    using CK = std::integral_constant<int, KIND>;
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using C3 = std::integral_constant<int, 3>;
-    using C6 = std::integral_constant<int, 6>;
-    using U0 = std::integral_constant<unsigned, 0u>;
-    // a whole quarter outside the stages (prologue)
-    auto quarter = [&](const char *src, char *slot, int xlim) {
-        if constexpr (KIND < 2) {
-            static_for<0, 3>([&](auto R) { raw_read(CK{}, R, src); });
-            raw_mask(xlim);
-            static_for<0, 3>([&](auto G) { pass6(G); });
-            quads_io(CK{}, CT{}, slot, C0{}, C6{});
-        } else {
-            quads_io(CK{}, CF{}, slot, C0{}, C6{});
-            static_for<0, 3>([&](auto G) { pass6(G); });
-            quads_io(CK{}, CT{}, slot, C0{}, C6{});
+    // quad q of the fragment order = positions xi = 4 q .. 4 q + 3; position (i, j) sits at xi_of(i, j), its value in dd[6 i + j]
+    auto v_write = [&](char *dst, auto Q_) {
+        constexpr int q = decltype(Q_)::value;
+        if constexpr (!(W4_ABL & 2))
+        {
+#ifdef W4_VW32
+            static_for<0, 4>([&](auto E_) { constexpr int e = decltype(E_)::value; *reinterpret_cast<float *>(dst + q * 2048 + e * 4) = dd[w4p_dd_of(4 * q + e)]; });
+#else
+            *reinterpret_cast<f32x4 *>(dst + q * 2048) = f32x4{dd[w4p_dd_of(4 * q)], dd[w4p_dd_of(4 * q + 1)], dd[w4p_dd_of(4 * q + 2)], dd[w4p_dd_of(4 * q + 3)]};
+#endif
         }
     };
-    // ---- prologue: raw slices 0..2 and U(stage 0) of the first item; V(stage 0) whole, the row pass of V(stage 1); raw slice 3 ----
+
+    // A run-time "which quarter now" around the stage bodies joins 144 accumulators in phi nodes and the register allocator gives up: the item loop exists
+    // four times (one copy per PH, unrolled by four stages with the quarters fixed at compile time) and a wave picks its copy once.
+    auto run = [&](auto PH_) {
+    constexpr int PH = decltype(PH_)::value;
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using U0 = std::integral_constant<unsigned, 0u>;
+    // where this wave parks across an epilogue: six parkers (three per block tile) x 9 KiB = U slot 1 (idle behind the last stage's closing barrier) + the spare 18 KiB
+    const unsigned park_u = (bt * 3 + PH - 1) < 4 ? U_BASE + U_BYTES + (unsigned)(bt * 3 + PH - 1) * 9216u : SPARE_BASE + (unsigned)(bt * 3 + PH - 1 - 4) * 9216u;
+    auto park = [&]() {
+        char *pa = ldsb + (lin() + park_u);
+        static_for<0, 9>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            *reinterpret_cast<f32x4 *>(pa + q * 1024) = f32x4{dd[4 * q], dd[4 * q + 1], dd[4 * q + 2], dd[4 * q + 3]};
+        });
+    };
+    auto unpark = [&]() {
+        const char *pa = ldsb + (lin() + park_u);
+        static_for<0, 9>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pa + q * 1024);
+            dd[4 * q] = v[0]; dd[4 * q + 1] = v[1]; dd[4 * q + 2] = v[2]; dd[4 * q + 3] = v[3];
+        });
+    };
+    // a whole quarter outside the stages (kernel prologue)
+    auto quarter = [&](auto Q_, const char *src, char *dst, int xlim) {
+        constexpr int q = decltype(Q_)::value;
+        if constexpr (q == 0) {
+            static_for<0, 6>([&](auto I) { raw_read(src, I); });
+            raw_mask(xlim);
+        }
+        if constexpr (q < 2) static_for<3 * q, 3 * q + 3>([&](auto I) { row_pass(I); });
+        else static_for<3 * (q - 2), 3 * (q - 2) + 3>([&](auto J) { col_pass(J); });
+        if constexpr (q == 3) static_for<0, 9>([&](auto Q) { v_write(dst, Q); });
+    };
+    // ---- kernel prologue: raw slices 0..2 and U(stage 0) of the first item; the quarters that precede stage 0 (slice 0 whole -> V slot 0, slice 1 Q0..Q2,
+    //      slice 2 Q0 Q1); raw slices 3..5; slice 3 Q0 ----
     tile_offsets(item_of(0));
     int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
     for (int sl = 0; sl < 3; sl++) {
@@ -367,34 +351,44 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (KIND < 2) quarter(ldsb + tr_rd, ldsb + tr_wr, xlim_cur);                          // rows of slice 0 -> slot 0
+    if constexpr (PH < 3) {
+        const char *src = ldsb + PH * RAW_BYTES + tr_rd();
+        static_for<0, 4 - PH>([&](auto Q) { quarter(Q, src, ldsb + tr_wr(), xlim_cur); });
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    dma_raw(C0{}, 0u, 3);   // (waited for by the first stage's closing wait: the row pass of the second stage reads it)
-    if (wave < 3) dma_raw(C1{}, 0u, 3);
-    if constexpr (KIND < 2) quarter(ldsb + RAW_BYTES + tr_rd, ldsb + tr_wr + V_BYTES, xlim_cur);    // rows of slice 1 -> slot 1
-    else quarter(nullptr, ldsb + tr_wr, 0);                                                          // columns of slot 0: V(stage 0)
+    for (int sl = 3; sl < 6; sl++) {
+        dma_raw(C0{}, (unsigned)(sl - 3) * RAW_BYTES, sl);
+        if (wave < 3) dma_raw(C1{}, (unsigned)(sl - 3) * RAW_BYTES, sl);
+    }
+    W2XC_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (PH == 3) quarter(C0{}, ldsb + tr_rd(), nullptr, xlim_cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // MFMA operand quads (four xi per ds_read_b128 and operand), read two groups of four MFMAs ahead, three register buffers each.  The closing wait and
-    // the barrier of a stage sit in front of its LAST group: behind the barrier the wave reads the first two groups of the NEXT stage and still has four
-    // MFMAs of this one to issue while they arrive -- with the barrier behind the last MFMA every stage began with an exposed LDS round trip (~400 of
-    // ~3000 cycles, s_memtime).
-    f32x4 a4[3], b4[3];
-    auto load_first = [&](unsigned u_slot, unsigned v_off) {
-        const char *ua = ldsb + ua0 + u_slot * U_BYTES;
-        const char *va = ldsb + va0 + v_off;
-        static_for<0, 2>([&](auto G) {
+    // MFMA operand quads (four xi per ds_read_b128 and operand), read W4_PF groups of four MFMAs ahead.  The closing wait and the barrier of a stage sit in
+    // front of its LAST group: behind the barrier the wave reads the first group(s) of the NEXT stage and still has four MFMAs of this one to issue
+    // while they arrive -- with the barrier behind the last MFMA every stage began with an exposed LDS round trip (~400 of ~3000 cycles, s_memtime).
+    constexpr int PF = W4_PF;
+    static_assert(PF == 1 || PF == 2, "operand look-ahead");
+    f32x4 a4[PF + 1], b4[PF + 1];
+    // register buffer of operand group g of a stage of parity par: g mod 3 with two groups of look-ahead; with one, two buffers whose roles swap with the
+    // stage's parity (group 8 and the next stage's group 0 are alive together)
+    auto load_first = [&](unsigned slot) {
+        const char *ua = ldsb + (lin() + (ua_u + slot * U_BYTES));
+        const char *va = ldsb + (lin() + (va_u + slot * V_BYTES));
+        static_for<0, PF>([&](auto G) {
             constexpr int g = decltype(G)::value;
-            a4[g] = *reinterpret_cast<const f32x4 *>(ua + g * 4096);
-            b4[g] = *reinterpret_cast<const f32x4 *>(va + g * 2048);
+            const int b = PF == 2 ? g : (int)slot;
+            a4[b] = *reinterpret_cast<const f32x4 *>(ua + g * 4096);
+            b4[b] = *reinterpret_cast<const f32x4 *>(va + g * 2048);
         });
     };
-    unsigned v0 = 0, v1 = V_BYTES, v2 = 2 * V_BYTES;   // byte offsets of the V slots of stages g, g + 1, g + 2
-    unsigned r0 = 0, r1 = RAW_BYTES, r2 = 2 * RAW_BYTES;   // ... of the raw buffers of the slices of stages g (= g + 3), g + 1 (= g + 4: this stage's transfer), g + 2 (the row pass reads it)
+    unsigned rd = RAW_BYTES, mid = 2 * RAW_BYTES, fr = 0;   // raw buffers of slice s + 4 (Q0 reads it), s + 5, and the one Q0 of the last stage has read (this stage's transfer: s + 6)
     int stamp = 0;
     (void)stamp;
     W4_STAMP(stamp++);
@@ -404,38 +398,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 #pragma unroll
         for (int xi = 0; xi < 36; xi++) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // one stage; J = global stage count mod 2 (NST is even: = s mod 2) = its U slot
+        // one stage; J = global stage count mod 4 (NST is a multiple of 4: = s mod 4)
         auto stage = [&](auto J_, int s) {
             constexpr int J = decltype(J_)::value;
-            constexpr unsigned par = J & 1, nxt = par ^ 1u;
+            constexpr int QT = (J - PH) & 3;                                              // this wave's quarter, of slice s + 4 - QT
+            constexpr unsigned par = J & 1, nxt = par ^ 1u;                               // U / V slot of this stage and of the next
             int u_ob = item % NOB, u_s = s + 1;
             if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
-            const char *ua = ldsb + ua0 + par * U_BYTES;
-            const char *va = ldsb + va0 + v0;
-            const char *srcA = ldsb + r2 + tr_rd;
-            char *slotA = ldsb + tr_wr + v2;
-            char *slotB = ldsb + tr_wr + v1;
-            const int xlimA = s + 2 < NST ? xlim_cur : xlim_r;
-            if constexpr (J == 0) {
-                if (s == NST - 4) tile_offsets(item_n);   // from this stage on the raw cursor (four stages ahead) is in the next item's tile
+            const char *ua = ldsb + (lin() + (ua_u + par * U_BYTES));
+            const char *va = ldsb + (lin() + (va_u + par * V_BYTES));
+            const char *srcQ = nullptr;
+            char *dstQ = nullptr;
+            if constexpr (QT == 0) srcQ = ldsb + (rd + tr_rd());
+            if constexpr (QT == 3) dstQ = ldsb + (tr_wr() + nxt * V_BYTES);
+            const int xlimQ = s + 4 < NST ? xlim_cur : xlim_r;
+            if constexpr (J == 2) {
+                if (s == NST - 6) tile_offsets(item_n);   // from this stage on the raw cursor (six slices ahead) is in the next item's tile
             }
-            const int r_slice = s + 4 < NST ? s + 4 : s + 4 - NST;
-            // operands of four xi per ds_read_b128; the quads of the next four xi are read while these four multiply
-            constexpr int PF = 2;
-            // this wave's quarter of the input transform
-            auto tr_reads = [&]() {
-                if constexpr (KIND < 2) static_for<0, 3>([&](auto R) { raw_read(CK{}, R, srcA); });
-                else quads_io(CK{}, CF{}, slotB, C0{}, C6{});
-            };
-            auto tr_mask = [&]() { if constexpr (KIND < 2) raw_mask(xlimA); };
-            auto tr_writes = [&](auto F_, auto L_) { quads_io(CK{}, CT{}, KIND < 2 ? slotA : slotB, F_, L_); };
+            const int r_slice = s + 6 < NST ? s + 6 : s + 6 - NST;
             static_for<0, 36>([&](auto XI) {
                 constexpr int xi = decltype(XI)::value;
+                constexpr int g = xi >> 2;
                 if constexpr (xi == 32) {
                     // ---- the stage's close, in front of its last four MFMAs ----
                     W4_STAMP(stamp++);
-                    // U of the next stage and the raw slice of stage g + 3 (issued one stage ago) have landed; this stage's raw pieces -- the youngest
-                    // transfers -- may still fly
+                    // U of the next stage and the raw slice issued one stage ago (Q0 of the NEXT stage reads it) have landed; this stage's raw pieces --
+                    // the youngest transfers -- may still fly
                     if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
                     else if (wave < 3) W2XC_WAIT_VMCNT(2);
                     else W2XC_WAIT_VMCNT(1);
@@ -443,68 +431,85 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     W4_STAMP(stamp++);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    { const unsigned tv = v0; v0 = v1; v1 = v2; v2 = tv; }
-                    { const unsigned tr = r0; r0 = r1; r1 = r2; r2 = tr; }
-                    if (s != NST - 1) load_first(nxt, v0);   // (an item's last stage: the epilogue comes first, the item loop reads them)
+                    { const unsigned tr = rd; rd = mid; mid = fr; fr = tr; }
+                    if (s != NST - 1) {                     // (an item's last stage: the epilogue comes first, the item loop reads them)
+                        if constexpr (PF == 2) load_first(nxt);
+                        else {
+                            a4[nxt] = *reinterpret_cast<const f32x4 *>(ldsb + (lin() + (ua_u + nxt * U_BYTES)));
+                            b4[nxt] = *reinterpret_cast<const f32x4 *>(ldsb + (lin() + (va_u + nxt * V_BYTES)));
+                        }
+                    }
                     W4_STAMP(stamp++);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr ((xi & 3) == 0 && (xi >> 2) + PF < 9 && !(W4_ABL & 128)) {
-                    a4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(ua + ((xi >> 2) + PF) * 4096);
-                    b4[((xi >> 2) + PF) % (PF + 1)] = *reinterpret_cast<const f32x4 *>(va + ((xi >> 2) + PF) * 2048);
+                if constexpr ((xi & 3) == 0 && g + PF < 9 && !(W4_ABL & 128)) {
+                    constexpr int b = PF == 2 ? (g + PF) % 3 : ((g + 1 + (int)par) & 1);
+                    a4[b] = *reinterpret_cast<const f32x4 *>(ua + (g + PF) * 4096);
+                    b4[b] = *reinterpret_cast<const f32x4 *>(va + (g + PF) * 2048);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(xi >> 2) % (PF + 1)][xi & 3], b4[(xi >> 2) % (PF + 1)][xi & 3], acc[xi], 0, 0, 0);
+                {
+                    constexpr int b = PF == 2 ? g % 3 : ((g + (int)par) & 1);
+                    // (as an instruction with the accumulator tied: left to the register allocator, most of these MFMAs get a destination other than
+                    // their accumulator input, the 144 accumulators migrate through the file and some are spilled inside the stages)
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[xi]) : "v"(a4[b][xi & 3]), "v"(b4[b][xi & 3]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // the stage's other work, behind the first MFMA slots: transfers (U pieces first, the raw pieces last: the closing wait leaves them in
                 // flight), then this wave's quarter of the input transform
-                {
-                    if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
-                        dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr (xi == 9 && !(W4_ABL & 16)) {
-                        if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr (xi == 11 && !(W4_ABL & 32)) {
-                        dma_raw(C0{}, r1, r_slice);                // slice of stage g + 4 into the buffer the row pass of stage g - 1 has read
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr (xi == 13 && !(W4_ABL & 32)) {
-                        if (wave < 3) dma_raw(C1{}, r1, r_slice);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // this wave's quarter of the input transform
-                    if constexpr (xi == 0) {
-                        tr_reads();
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi >= W4P_T0 && xi < W4P_T0 + 3) {
-                        if constexpr (xi == W4P_T0) tr_mask();
-                        pass6(std::integral_constant<int, xi - W4P_T0>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi == W4P_T0 + 3) {
-                        tr_writes(C0{}, C3{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if constexpr (xi == W4P_T0 + 4) {
-                        tr_writes(C3{}, C6{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
+                    dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 9 && !(W4_ABL & 16)) {
+                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 11 && !(W4_ABL & 32)) {
+                    dma_raw(C0{}, fr, r_slice);                // slice s + 6 into the buffer Q0 of stage s - 1 has read
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi == 13 && !(W4_ABL & 32)) {
+                    if (wave < 3) dma_raw(C1{}, fr, r_slice);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (QT == 0 && xi < 2) {
+                    raw_read(srcQ, std::integral_constant<int, 3 * xi>{});
+                    raw_read(srcQ, std::integral_constant<int, 3 * xi + 1>{});
+                    raw_read(srcQ, std::integral_constant<int, 3 * xi + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (xi >= W4P_T0 && xi < W4P_T0 + 3) {
+                    if constexpr (QT == 0 && xi == W4P_T0) raw_mask(xlimQ);
+                    if constexpr (QT < 2) row_pass(std::integral_constant<int, 3 * QT + xi - W4P_T0>{});
+                    else col_pass(std::integral_constant<int, 3 * (QT - 2) + xi - W4P_T0>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (QT == 3 && xi >= W4P_T0 + 3 && xi < W4P_T0 + 6) {
+                    v_write(dstQ, std::integral_constant<int, 3 * (xi - (W4P_T0 + 3))>{});
+                    v_write(dstQ, std::integral_constant<int, 3 * (xi - (W4P_T0 + 3)) + 1>{});
+                    v_write(dstQ, std::integral_constant<int, 3 * (xi - (W4P_T0 + 3)) + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
         };
-        load_first(0u, v0);
+        load_first(0u);
 #pragma unroll 1
-        for (int s = 0; s < NST; s += 2) {
+        for (int s = 0; s < NST; s += 4) {
             stage(std::integral_constant<int, 0>{}, s);
             stage(std::integral_constant<int, 1>{}, s + 1);
+            stage(std::integral_constant<int, 2>{}, s + 2);
+            stage(std::integral_constant<int, 3>{}, s + 3);
         }
-        xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile three stages ago)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results: the hazard the compiler does not see through the asm)
+        xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile five stages ago)
+        if constexpr (PH != 0) park();   // (PH = 0 has just written the V of the next item's first stage)
         {
             // ---- epilogue: Y = A^T M A, bias, LeakyReLU, stores.  C/D of the 16x16 MFMA: lane & 15 = block, register e = plane
             //      4 (lane >> 4) + e of the plane tile ----
             __builtin_amdgcn_s_setprio(2);
             const int ob = item % NOB;
+            const int lane_e = lane_o(), t = lane_e & 15, k = lane_e >> 4;
             int tile_y, tile_x;
             tile_coords(item / NOB, tile_y, tile_x);
             const int ty0 = tile_y * ROWS - d.wino_py;
@@ -521,11 +526,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             // instead of 512, and conv3x3_last_gather adds taps and blocks (0.1 ms instead of the 0.8 ms of conv3x3_last).
             float a7[4];
             if constexpr (FUSE7) {
-                const float *w7 = reinterpret_cast<const float *>(d.w7pk) + (size_t)(ob * 4 + pt) * 256 + lane;   // [16-plane group][e][lane]
+                const float *w7 = reinterpret_cast<const float *>(d.w7pk) + (size_t)(ob * 4 + pt) * 256 + lane_e;   // [16-plane group][e][lane]
 #pragma unroll
                 for (int e = 0; e < 4; e++) a7[e] = w7[e * 64];
             }
-            char *red = ldsb + V_BASE + v2;   // [pt][tap quad 0 / 1][128 pixels][4] (16 KiB) + [pt][128 pixels] for tap 8 (2 KiB)
+            char *red = ldsb + V_BASE + V_BYTES;   // (V slot 1: idle until the next item's first stage writes V of its second)
+            // [pt][tap quad 0 / 1][128 pixels][4] (16 KiB) + [pt][128 pixels] for tap 8 (2 KiB)
             // Two output ROWS of the block at a time (the row transform of a column per row PAIR: 7 operations instead of 10 for all four rows):
             // 48 + 16 live values beside the 144 accumulators.
 #pragma unroll
@@ -582,7 +588,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                         {
-                            const int tid = threadIdx.x;
+                            const int tid = wave * 64 + lane_e;
                             if (tid < 384) {
                                 const int p = tid & 127, kq = tid >> 7;     // kq = 0, 1: taps 4 kq .. 4 kq + 3; kq = 2: tap 8
                                 const int gy = ty0 + 4 * (p >> 5) + i, gx = tile_x * 32 + (p & 31);
@@ -605,7 +611,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                             }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();   // (the slab is rewritten by the next row; after the last row the next item's row passes park here)
+                        __builtin_amdgcn_s_barrier();   // (the slab is rewritten by the next row)
                         asm volatile("" ::: "memory");
                     } else if constexpr ((W4_ABL & 64) != 0) {
                         if (y[0][0] == 12345.678f) *reinterpret_cast<f32x4 *>(obase) = y[0] + y[1] + y[2] + y[3];
@@ -628,10 +634,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             __builtin_amdgcn_s_setprio(0);
             W4_STAMP(stamp++);
         }
+        // the transforms in flight back into registers; the barrier: the next stage's U transfers land on the parking area
+        if constexpr (PH != 0) unpark();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
     };
-    switch (pt) {
+    switch ((pt - 2 * bt) & 3) {
     case 0: run(std::integral_constant<int, 0>{}); break;
     case 1: run(std::integral_constant<int, 1>{}); break;
     case 2: run(std::integral_constant<int, 2>{}); break;
