@@ -64,6 +64,9 @@ __device__ unsigned long long w4_stamps[2][8192];
 #ifndef W4_PF
 #define W4_PF 2      // operand look-ahead in groups of four MFMAs (1: two register buffers, 2: three)
 #endif
+#ifndef W4_DMA4
+#define W4_DMA4 1    // 1: the four OLDER waves (block tile 0) issue every transfer (nine U pieces + two / three raw pieces each per stage), the younger four none
+#endif
 #ifndef W4_ABL
 #define W4_ABL 0   // timing-only ablations (wrong results): 1 no transform arithmetic | 2 no transform at all | 16 no U transfers | 32 no raw transfers | 64 no epilogue stores | 128 no operand reads inside the stages
 #endif
@@ -155,9 +158,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 
     for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
 
-    // ---- raw tile transfers: chunk ci = piece * 64 + lane -> (channel kk, row R, quad q); wave w sends pieces w and (w < 3) 8 + w ----
+    // ---- raw tile transfers: chunk ci = piece * 64 + lane -> (channel kk, row R, quad q); wave w < DW sends pieces w, w + DW, ... ----
     const long long cs4 = d.in_cs * 4, rs4 = d.in_rs * 4;     // bytes
-    unsigned voff[2];
+    constexpr int DW = W4_DMA4 ? 4 : 8;                        // waves that issue transfers
+    constexpr int RJ = (RAW_PIECES + DW - 1) / DW;             // raw pieces per such wave (the last one: waves < RAW_PIECES - (RJ - 1) * DW = 3 only)
+    constexpr int UQ = 36 / DW + (36 % DW ? 1 : 0);            // U pieces per such wave (8 waves: the fifth from waves < 4 only)
+    unsigned voff[RJ];
     const char *a_base;
     int xlim_r;                                                // in_w - x0 of the tile the raw cursor is in (patch columns >= it are outside the plane)
     auto tile_offsets = [&](int it) {
@@ -174,8 +180,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             // position are consecutive chunks (conflict-free ds_read_b32 of a lane's channel); columns clamped (replicate) like the rows
             xlim_r = 64;   // (nothing to mask)
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                int ci = (jj * 8 + wave) * 64 + lane_t;
+            for (int jj = 0; jj < RJ; jj++) {
+                int ci = (jj * DW + wave) * 64 + lane_t;
                 ci = ci < (ROWS + 2) * 36 ? ci : (ROWS + 2) * 36 - 1;
                 const int R = ci / 36, slot = ci - R * 36;
                 const int x = 4 * (slot % 9) + slot / 9;
@@ -187,8 +193,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         }
         const int xq_last = (d.in_w - 1) & ~3;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int ci = (jj * 8 + wave) * 64 + lane_t;
+        for (int jj = 0; jj < RJ; jj++) {
+            const int ci = (jj * DW + wave) * 64 + lane_t;
             int kk = ci / CHS;
             kk = kk < 4 ? kk : 3;
             const int rem = ci - kk * CHS;
@@ -208,15 +214,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     auto dma_raw = [&](auto JJ, unsigned roff, int slice) {
         constexpr int jj = decltype(JJ)::value;
         const char *sbase = a_base + (long long)slice * (IN_NHWC ? 16 : 4 * cs4);
-        lds_dma16_si<jj * 8192u>(sbase, voff[jj], wbase + roff);
+        lds_dma16_si<jj * DW * 1024u>(sbase, voff[jj], wbase + roff);
     };
-    // U of (64-plane block ob, stage s_): 36 pieces of 1 KiB (one per xi); wave w sends xi = w, w + 8, w + 16, w + 24 and (w < 4) 32 + w
+    // U of (64-plane block ob, stage s_): 36 pieces of 1 KiB (one per xi); wave w < DW sends xi = w, w + DW, ...
     const char *wpk_w = reinterpret_cast<const char *>(d.wpk) + (size_t)wave * 1024;
-    auto dma_u = [&](int ob, int s_, auto SLOT, auto Q) {     // piece xi = 8 q + wave
+    auto dma_u = [&](int ob, int s_, auto SLOT, auto Q) {     // piece xi = DW q + wave
         constexpr unsigned slot = decltype(SLOT)::value;
         constexpr int q = decltype(Q)::value;
-        const char *sbase = wpk_w + ((size_t)(ob * NST + s_) * 36 + q * 8) * 1024;
-        lds_dma16_si<U_BASE + slot * U_BYTES + q * 8192u>(sbase, b_voff, wbase);
+        const char *sbase = wpk_w + ((size_t)(ob * NST + s_) * 36 + q * DW) * 1024;
+        lds_dma16_si<U_BASE + slot * U_BYTES + q * DW * 1024u>(sbase, b_voff, wbase);
     };
 
     // ---- addressing ----
@@ -339,14 +345,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     //      slice 2 Q0 Q1); raw slices 3..5; slice 3 Q0 ----
     tile_offsets(item_of(0));
     int xlim_cur = xlim_r;                                      // in_w - x0 of the current item's tile
-    for (int sl = 0; sl < 3; sl++) {
-        dma_raw(C0{}, (unsigned)sl * RAW_BYTES, sl);
-        if (wave < 3) dma_raw(C1{}, (unsigned)sl * RAW_BYTES, sl);
-    }
-    {
+    auto raw_all = [&](unsigned roff, int slice) {              // this wave's pieces of a slice
+        if (wave < DW) {
+            static_for<0, RJ - 1>([&](auto JJ) { dma_raw(JJ, roff, slice); });
+            if (wave < RAW_PIECES - (RJ - 1) * DW) dma_raw(std::integral_constant<int, RJ - 1>{}, roff, slice);
+        }
+    };
+    for (int sl = 0; sl < 3; sl++) raw_all((unsigned)sl * RAW_BYTES, sl);
+    if (wave < DW) {
         const int ob0 = item_of(0) % NOB;
-        static_for<0, 4>([&](auto Q) { dma_u(ob0, 0, U0{}, Q); });
-        if (wave < 4) dma_u(ob0, 0, U0{}, std::integral_constant<int, 4>{});
+        static_for<0, UQ - 1>([&](auto Q) { dma_u(ob0, 0, U0{}, Q); });
+        if (wave < 36 - (UQ - 1) * DW) dma_u(ob0, 0, U0{}, std::integral_constant<int, UQ - 1>{});
     }
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
@@ -358,10 +367,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int sl = 3; sl < 6; sl++) {
-        dma_raw(C0{}, (unsigned)(sl - 3) * RAW_BYTES, sl);
-        if (wave < 3) dma_raw(C1{}, (unsigned)(sl - 3) * RAW_BYTES, sl);
-    }
+    for (int sl = 3; sl < 6; sl++) raw_all((unsigned)(sl - 3) * RAW_BYTES, sl);
     W2XC_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -425,8 +431,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     // U of the next stage and the raw slice issued one stage ago (Q0 of the NEXT stage reads it) have landed; this stage's raw pieces --
                     // the youngest transfers -- may still fly
                     if constexpr ((W4_ABL & 32) != 0) W2XC_WAIT_VMCNT(0);
-                    else if (wave < 3) W2XC_WAIT_VMCNT(2);
-                    else W2XC_WAIT_VMCNT(1);
+                    else if (wave < RAW_PIECES - (RJ - 1) * DW) wait_vmcnt_n(RJ);
+                    else if (wave < DW) wait_vmcnt_n(RJ - 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     W4_STAMP(stamp++);
                     __builtin_amdgcn_s_barrier();
@@ -457,20 +463,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 __builtin_amdgcn_sched_barrier(0);
                 // the stage's other work, behind the first MFMA slots: transfers (U pieces first, the raw pieces last: the closing wait leaves them in
                 // flight), then this wave's quarter of the input transform
-                if constexpr ((xi == 1 || xi == 3 || xi == 5 || xi == 7) && !(W4_ABL & 16)) {
-                    dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, ((xi - 1) >> 1)>{});
+                constexpr int TSTEP = W4_DMA4 ? 1 : 2, tk = xi >= 1 && (xi - 1) % TSTEP == 0 ? (xi - 1) / TSTEP : -1;   // transfer slot behind MFMA xi
+                if constexpr (tk >= 0 && tk < UQ && !(W4_ABL & 16)) {
+                    constexpr int q = tk;
+                    if (wave < (q == UQ - 1 ? 36 - (UQ - 1) * DW : DW)) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, q>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (xi == 9 && !(W4_ABL & 16)) {
-                    if (wave < 4) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, 4>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 11 && !(W4_ABL & 32)) {
-                    dma_raw(C0{}, fr, r_slice);                // slice s + 6 into the buffer Q0 of stage s - 1 has read
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (xi == 13 && !(W4_ABL & 32)) {
-                    if (wave < 3) dma_raw(C1{}, fr, r_slice);
+                if constexpr (tk >= UQ && tk < UQ + RJ && !(W4_ABL & 32)) {
+                    constexpr int jj = tk - UQ;      // slice s + 6 into the buffer Q0 of stage s - 1 has read
+                    if (wave < (jj == RJ - 1 ? RAW_PIECES - (RJ - 1) * DW : DW)) dma_raw(std::integral_constant<int, jj>{}, fr, r_slice);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (QT == 0 && xi < 2) {
