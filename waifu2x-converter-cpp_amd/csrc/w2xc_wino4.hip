@@ -26,7 +26,8 @@
 //              chunk index kk * 168 + R * 9 + q (the stride 168 = 8 mod 16 makes the b128 patch reads conflict-free);
 //              U[2] x 36 KiB + V[2] x 18 KiB + 18 KiB (with U slot 1 the parking area of an epilogue) + bias = 159.5 KiB.
 //   Transfers  LDS-DMA (global_load_lds_dwordx4), SGPR base + 32-bit lane offset: per stage 36 U pieces (one stage ahead) and 11 raw
-//              pieces (the slice Q0 reads two stages later; the closing wait of a stage leaves its own raw pieces in flight).  A lane's 16 bytes are four
+//              pieces (the slice Q0 reads two stages later; the closing wait of a stage leaves its own raw pieces in flight), all issued by the
+//              four OLDER waves: they win the matrix pipe's arbitration and have the time (W4_DMA4).  A lane's 16 bytes are four
 //              consecutive pixels of one plane row: whole 128-byte lines (the engine gives planar rows a stride of roundup32(w) floats).
 //   32 planes in  (IN_NHWC) the producers conv3x3_first / conv3x3_wino write NHWC pixels of one 128-byte line: a raw chunk is then the four
 //              channels of ONE pixel, the pixels of a row grouped by column mod 4 (conflict-free ds_read_b32 of a lane's channel).
