@@ -401,13 +401,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     W4_STAMP(stamp++);
     for (int n = 0; n < nmy; n++) {
         const int item = item_of(n), item_n = item_of(n + 1);
-        f32x4 acc[36];
-#pragma unroll
-        for (int xi = 0; xi < 36; xi++) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc[36];   // (first written by the item's first stage: its MFMAs take 0 as their accumulator input -- 144 v_mov per wave and item less)
 
         // one stage; J = global stage count mod 4 (NST is a multiple of 4: = s mod 4)
-        auto stage = [&](auto J_, int s) {
+        auto stage = [&](auto J_, auto FIRST_, int s) {
             constexpr int J = decltype(J_)::value;
+            constexpr bool FIRST = decltype(FIRST_)::value;   // the item's first stage
             constexpr int QT = (J - PH) & 3;                                              // this wave's quarter, of slice s + 4 - QT
             constexpr unsigned par = J & 1, nxt = par ^ 1u;                               // U / V slot of this stage and of the next
             int u_ob = item % NOB, u_s = s + 1;
@@ -459,7 +458,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     constexpr int b = PF == 2 ? g % 3 : ((g + (int)par) & 1);
                     // (as an instruction with the accumulator tied: left to the register allocator, most of these MFMAs get a destination other than
                     // their accumulator input, the 144 accumulators migrate through the file and some are spilled inside the stages)
-                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[xi]) : "v"(a4[b][xi & 3]), "v"(b4[b][xi & 3]));
+                    if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc[xi]) : "v"(a4[b][xi & 3]), "v"(b4[b][xi & 3]));
+                    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[xi]) : "v"(a4[b][xi & 3]), "v"(b4[b][xi & 3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // the stage's other work, behind the first MFMA slots: transfers (U pieces first, the raw pieces last: the closing wait leaves them in
@@ -496,12 +496,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             });
         };
         load_first(0u);
+        // the loop, rotated by one stage: the first stage of the item is its own copy of the stage body (five copies instead of four)
+        stage(std::integral_constant<int, 0>{}, std::true_type{}, 0);
 #pragma unroll 1
-        for (int s = 0; s < NST; s += 4) {
-            stage(std::integral_constant<int, 0>{}, s);
-            stage(std::integral_constant<int, 1>{}, s + 1);
-            stage(std::integral_constant<int, 2>{}, s + 2);
-            stage(std::integral_constant<int, 3>{}, s + 3);
+        for (int s = 1; s < NST; s += 4) {
+            stage(std::integral_constant<int, 1>{}, std::false_type{}, s);
+            stage(std::integral_constant<int, 2>{}, std::false_type{}, s + 1);
+            stage(std::integral_constant<int, 3>{}, std::false_type{}, s + 2);
+            if (s + 3 < NST) stage(std::integral_constant<int, 0>{}, std::false_type{}, s + 3);
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results: the hazard the compiler does not see through the asm)
         xlim_cur = xlim_r;   // (the raw cursor entered the next item's tile five stages ago)
