@@ -14,7 +14,8 @@
 //   Stage      one 4-CHANNEL slice = the K of one MFMA: 36 MFMAs per wave, both operands from LDS in fragment order
 //              [xi / 4][tile][lane][xi % 4] (one ds_read_b128 per four xi and operand, read two groups of four MFMAs ahead; A = U, lane = 16 k + o;
 //              B = V, lane = 16 k + t).  The stage's closing wait + barrier sit in FRONT of its last four MFMAs: behind the barrier a wave reads the
-//              first operands of the next stage and still has four MFMAs to issue while they arrive.
+//              first operands of the next stage and still has four MFMAs to issue while they arrive.  An item's first stage is its own copy of the
+//              stage body: its MFMAs take 0 as accumulator input (no zeroing of 144 registers per wave and item).
 //   V          is computed once per (block, channel) and shared by the four plane-tile waves through LDS.  ONE wave transforms a 4-channel slice of
 //              its block tile in FOUR QUARTERS over four consecutive stages, the 36 values in REGISTERS in between (Q0 raw patch + row pass of rows
 //              0..2 | Q1 rows 3..5 | Q2 column pass of columns 0..2 | Q3 columns 3..5 + nine ds_write_b128 of V): every wave carries the same 42 VALU
@@ -39,9 +40,9 @@
 //              outputs >= out_w, and what is in memory there is not defined): results do not depend on memory contents outside the plane.
 //   Banding    blocks sit on rows = 0 mod 4 of the layer's whole output (W2xcConvDesc::wino_py = first row mod 4); run_rows' four-rows-per-layer
 //              band geometry makes every region edge that is not a plane edge a block edge: bit-identical results across bandings.
-// Measured (round 4, 2160x3840, one MI355X): 128 -> 128 6.5-6.8 ms (round 3's NHWC kernel: 7.5 on the same box), frame 14.4 ms (16.4).  s_memtime: a stage
-// takes ~3350 cycles (2304 = the matrix pipe's time for the 72 MFMAs of a SIMD), an item's first stage + epilogue another ~9.5k of its 117k
-// (profiles/r4_sweeps.log).
+// Measured (round 4, 2160x3840, one MI355X): 128 -> 128 6.4-6.8 ms (round 3's NHWC kernel: 7.5 on the same box), frame 14.4-14.9 ms (16.4).  s_memtime: a
+// stage takes ~3350 cycles (2304 = the matrix pipe's time for the 72 MFMAs of a SIMD; a synthetic loop of the same shape without transfers: 2670), an
+// item's boundary another ~8k of its 116k (profiles/r4_sweeps.log).
 #include "w2xc_kernels.h"
 #include "w2xc_device.h"
 
