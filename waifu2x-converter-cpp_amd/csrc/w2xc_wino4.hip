@@ -288,12 +288,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     auto row_pass = [&](auto I_) {                            // s[i][.] = d[i][.] B
         constexpr int i = decltype(I_)::value;
         if constexpr (!(W4_ABL & 3)) bt6(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
-        asm volatile("" : "+v"(dd[i * 6 + 0]), "+v"(dd[i * 6 + 1]), "+v"(dd[i * 6 + 2]), "+v"(dd[i * 6 + 3]), "+v"(dd[i * 6 + 4]), "+v"(dd[i * 6 + 5]));
+        if constexpr (!(W4_ABL & 3)) asm volatile("" : "+v"(dd[i * 6 + 0]), "+v"(dd[i * 6 + 1]), "+v"(dd[i * 6 + 2]), "+v"(dd[i * 6 + 3]), "+v"(dd[i * 6 + 4]), "+v"(dd[i * 6 + 5]));
     };
     auto col_pass = [&](auto J_) {                            // V[.][j] = B^T s[.][j]
         constexpr int j = decltype(J_)::value;
         if constexpr (!(W4_ABL & 3)) bt6(dd[0 * 6 + j], dd[1 * 6 + j], dd[2 * 6 + j], dd[3 * 6 + j], dd[4 * 6 + j], dd[5 * 6 + j]);
-        asm volatile("" : "+v"(dd[0 * 6 + j]), "+v"(dd[1 * 6 + j]), "+v"(dd[2 * 6 + j]), "+v"(dd[3 * 6 + j]), "+v"(dd[4 * 6 + j]), "+v"(dd[5 * 6 + j]));
+        if constexpr (!(W4_ABL & 3)) asm volatile("" : "+v"(dd[0 * 6 + j]), "+v"(dd[1 * 6 + j]), "+v"(dd[2 * 6 + j]), "+v"(dd[3 * 6 + j]), "+v"(dd[4 * 6 + j]), "+v"(dd[5 * 6 + j]));
     };
     // quad q of the fragment order = positions xi = 4 q .. 4 q + 3; position (i, j) sits at xi_of(i, j), its value in dd[6 i + j]
     auto v_write = [&](char *dst, auto Q_) {
