@@ -24,8 +24,10 @@ static __device__ __forceinline__ void bt6(float &x0, float &x1, float &x2, floa
     const float y5 = __builtin_fmaf(-2.8125f, x3, __builtin_fmaf(1.265625f, x1, x5));
     x0 = y0; x1 = p + q; x2 = p - q; x3 = u + v; x4 = u - v; x5 = y5;
 }
-// BIG: 32x32x2 (18 per stage) instead of 16x16x4 (36); LDSOPS: operand quads from LDS; VALU: the 42 transform instructions; BAR: the barrier
-template <bool BIG, bool LDSOPS, bool VALU, bool BAR>
+// BIG: 1 = 32x32x2 (18 per stage) instead of 16x16x4 (36); 2 = 27 x v_mfma_f32_16x16x16_f16 (three fp16 products per position: 9 positions x 16 channels, the same
+// operand bytes as one fp32 stage -- DESIGN.md 9.2); LDSOPS: operand quads from LDS; VALU: the 42 transform instructions; BAR: the barrier
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int BIG, bool LDSOPS, bool VALU, bool BAR>
 __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, int stages)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -34,10 +36,10 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, int sta
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const char *ua = reinterpret_cast<const char *>(lds) + (wave & 3) * 1024 + lane * 16;           // + g * 4096
     const char *va = reinterpret_cast<const char *>(lds) + 36864 + (wave >> 2) * 1024 + lane * 16;   // + g * 2048
-    constexpr int NQ = BIG ? 9 : 36;
-    typedef typename std::conditional<BIG, f32x16, f32x4>::type acc_t;
+    constexpr int NQ = BIG == 1 ? 9 : 36;
+    typedef typename std::conditional<BIG == 1, f32x16, f32x4>::type acc_t;
     acc_t acc[NQ];
-    for (int i = 0; i < NQ; i++) for (int e = 0; e < (BIG ? 16 : 4); e++) acc[i][e] = 0.0f;
+    for (int i = 0; i < NQ; i++) for (int e = 0; e < (BIG == 1 ? 16 : 4); e++) acc[i][e] = 0.0f;
     float dd[18];
     for (int i = 0; i < 18; i++) dd[i] = in[(lane + i) & 1023];
     f32x4 a4[3], b4[3];
@@ -55,13 +57,19 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, int sta
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (LDSOPS && (xi & 3) == 0 && g + 2 < 9 && (!BIG || (g & 1) == 0)) {   // (32x32x2: half the operand dwords per stage)
+            if constexpr (LDSOPS && (xi & 3) == 0 && g + 2 < 9 && (BIG != 1 || (g & 1) == 0)) {   // (32x32x2: half the operand dwords per stage)
                 a4[(g + 2) % 3] = *reinterpret_cast<const f32x4 *>(ua + (g + 2) * 4096);
                 b4[(g + 2) % 3] = *reinterpret_cast<const f32x4 *>(va + (g + 2) * 2048);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (!BIG) {
+            if constexpr (BIG == 0) {
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[xi]) : "v"(a4[g % 3][xi & 3]), "v"(b4[g % 3][xi & 3]));
+            } else if constexpr (BIG == 2) {
+                if constexpr (xi < 27) {   // position xi / 3, product xi % 3; an operand = four fp16 = half a quad
+                    const f16x4 av = __builtin_bit_cast(f16x4, __builtin_shufflevector(a4[g % 3], a4[g % 3], (xi & 1) * 2, (xi & 1) * 2 + 1));
+                    const f16x4 bv = __builtin_bit_cast(f16x4, __builtin_shufflevector(b4[g % 3], b4[g % 3], (xi & 1) * 2, (xi & 1) * 2 + 1));
+                    asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[xi / 3]) : "v"(av), "v"(bv));
+                }
             } else if constexpr ((xi & 1) == 0) {
                 asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[(xi >> 1) % 9]) : "v"(a4[g % 3][xi & 3]), "v"(b4[g % 3][xi & 3]));
             }
@@ -76,11 +84,11 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, int sta
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float sum = 0;
-    for (int i = 0; i < NQ; i++) for (int e = 0; e < (BIG ? 16 : 4); e++) sum += acc[i][e];
+    for (int i = 0; i < NQ; i++) for (int e = 0; e < (BIG == 1 ? 16 : 4); e++) sum += acc[i][e];
     for (int i = 0; i < 18; i++) sum += dd[i];
     out[blockIdx.x * 512 + threadIdx.x] = sum;
 }
-template <bool BIG, bool LDSOPS, bool VALU, bool BAR>
+template <int BIG, bool LDSOPS, bool VALU, bool BAR>
 static void run(const float *in, float *out, const char *name)
 {
     const int stages = 4000;
@@ -106,17 +114,20 @@ int main()
     (void)hipMalloc(&in, 4096); (void)hipMalloc(&out, 256 * 512 * 4);
     (void)hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; rep++) {
-        run<false, false, false, false>(in, out, "16x16x4: MFMA only");
-        run<false, false, false, true>(in, out, "16x16x4: + barrier");
-        run<false, true, false, true>(in, out, "16x16x4: + barrier + LDS operands");
-        run<false, false, true, true>(in, out, "16x16x4: + barrier + 42 VALU");
-        run<false, true, true, true>(in, out, "16x16x4: + barrier + LDS operands + 42 VALU");
-        run<false, true, true, false>(in, out, "16x16x4: LDS operands + 42 VALU, no barrier");
-        run<true, false, false, false>(in, out, "32x32x2: MFMA only");
-        run<true, false, false, true>(in, out, "32x32x2: + barrier");
-        run<true, true, false, true>(in, out, "32x32x2: + barrier + LDS operands");
-        run<true, false, true, true>(in, out, "32x32x2: + barrier + 42 VALU");
-        run<true, true, true, true>(in, out, "32x32x2: + barrier + LDS operands + 42 VALU");
+        run<0, false, false, false>(in, out, "16x16x4: MFMA only");
+        run<0, false, false, true>(in, out, "16x16x4: + barrier");
+        run<0, true, false, true>(in, out, "16x16x4: + barrier + LDS operands");
+        run<0, false, true, true>(in, out, "16x16x4: + barrier + 42 VALU");
+        run<0, true, true, true>(in, out, "16x16x4: + barrier + LDS operands + 42 VALU");
+        run<0, true, true, false>(in, out, "16x16x4: LDS operands + 42 VALU, no barrier");
+        run<1, false, false, false>(in, out, "32x32x2: MFMA only");
+        run<1, false, false, true>(in, out, "32x32x2: + barrier");
+        run<1, true, false, true>(in, out, "32x32x2: + barrier + LDS operands");
+        run<1, false, true, true>(in, out, "32x32x2: + barrier + 42 VALU");
+        run<1, true, true, true>(in, out, "32x32x2: + barrier + LDS operands + 42 VALU");
+        run<2, false, false, false>(in, out, "16x16x16 f16 x 27: MFMA only");
+        run<2, true, false, true>(in, out, "16x16x16 f16 x 27: + barrier + LDS operands");
+        run<2, true, true, true>(in, out, "16x16x16 f16 x 27: + barrier + LDS operands + 42 VALU");
     }
     return 0;
 }
