@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric:
 "Mpixels/sec end-to-end scale2.0x 7-layer conv, 1/2/4/8 GPU + host-CPU baseline").
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one convertWithModels pass (7 layers: pad-7 by clamped loads, 7 kernel launches, crop/stitch
@@ -36,11 +36,12 @@ Extra objects on the JSON line:
                are what the MFMA pipe really does: the FLOPs the kernel ISSUES (1/4 resp. 16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
                reproducible from profiles/r4_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
                time) is carried beside it as `algorithmic_tflops` / `algorithmic_speedup_vs_direct_roofline` (> 1 means
-               faster than ANY direct convolution could be on this MFMA).  w2xc_opts.kernel = W2XC_KERNEL_MFMA (or
-               W2XC_WINOGRAD=0) runs conv3x3_mfma2, where executed = algorithmic.
+               faster than ANY direct convolution could be on this MFMA).  w2xc_opts.kernel = W2XC_KERNEL_MFMA runs
+               conv3x3_mfma2, where executed = algorithmic.  A fused last layer is counted at its useful FLOPs (2 x 9 x Cin per pixel).
                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same command
                (profiles/r4_roofline.json), only when that profile was taken from the kernel sources being run
                (hash check), else null.
+  parity_patch_max_rel_err   one border and one interior 48x48 patch of the plane that was TIMED against the CPU oracle (the checker).
   cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real binary cannot be
                built) timed on this host's cores on a bounded sample of whole 512^2 blocks of the same plane.
 """
@@ -155,6 +156,45 @@ def cpu_baseline(layers, plane, budget_s=15.0):
     return res
 
 
+def self_launch(n, ndev):
+    """`python bench.py --gpus N` WITHOUT a launcher: re-exec this command line under torch.distributed.run, one rank per GPU
+    (--master-addr 127.0.0.1, a free port), so that a plain invocation cannot fail for a launcher reason.  RCCL cannot put two ranks
+    on one device: on a box with fewer than N devices the ranks share them and the barrier / MAX run over gloo (the record says so in
+    `backend` and `rank_devices`; the data path has no collective either way)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < n:
+        env.setdefault("W2XC_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def parity_patches(layers, plane_rows_of, d_out, ra, rb, H, W, n_layers):
+    """The plane that was TIMED against the CPU oracle (the checker, never the thing measured): one 48x48 patch on the plane's border
+    and one in the interior of this rank's rows, each from a crop with the network's halo (convertRoutine.cpp:84-169's own argument).
+    Returns max |gpu - oracle| / max |oracle| over both patches and whether every element is inside rtol 1e-4 + atol 1e-5."""
+    from oracle import oracle as orc
+    o = orc.Oracle(layers)
+    ph = min(48, rb - ra)
+    pw = min(48, W)
+    spots = [(ra, 0), (ra + max(0, (rb - ra) // 2 - ph // 2), max(0, W // 2 - pw // 2))]
+    worst, ok = 0.0, True
+    for (y, x) in spots:
+        y0, y1, x0, x1 = max(0, y - n_layers), min(H, y + ph + n_layers), max(0, x - n_layers), min(W, x + pw + n_layers)
+        sub = o.convert(np.ascontiguousarray(plane_rows_of(y0, y1)[:, x0:x1]), block_splitting=False, njob=min(8, os.cpu_count() or 1))
+        want = sub[y - y0:y - y0 + ph, x - x0:x - x0 + pw]
+        got = d_out[y - ra:y - ra + ph, x:x + pw].cpu().numpy()
+        worst = max(worst, float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)))
+        ok = ok and bool(np.allclose(got, want, rtol=1e-4, atol=1e-5))
+    return worst, ok, spots
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,8 +228,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            self_launch(args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0)   # (does not return)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the product path has no CPU fallback)")
@@ -323,6 +363,11 @@ def main():
     rank_dev = per_rank(float(torch.cuda.current_device()))
     layer_ms, launches = ms.profile_read(dev_index)
     ok = bool(torch.isfinite(d_out.float()).all().item())
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline and workload != "image_u8":
+        # the CPU oracle as the CHECKER of the plane just timed (never inside a timed region)
+        rows_of = lambda a, b: nn2x(y_src[a // 2:(b + 1) // 2])[a - 2 * (a // 2):][:b - a]
+        parity = parity_patches(layers, rows_of, d_out, ra, rb, H, W, n_layers)
     if args.dump_out:
         os.makedirs(args.dump_out, exist_ok=True)
         np.savez(os.path.join(args.dump_out, "rank%d.npz" % rank), ra=ra, rb=rb, rows=d_out.cpu().numpy())
@@ -499,7 +544,8 @@ def main():
         algorithmic = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # a fused last layer's MFMAs are issued by the dominant kernel too (taps-as-rows on 16x16x4 tiles: 16 rows x cin per pixel, 9 of them useful)
         fused_last = dom + 1 == n_layers - 1 and ms.kernel_name(dom + 1, opts) == "conv3x3_last_gather" and args.precision == "fp32"
-        fused_flops = (2.0 * 16 * ms.planes(dom + 1)[0] * dom_flops / (18.0 * ms.planes(dom)[0] * ms.planes(dom)[1])) if fused_last else 0.0
+        # counted at its 9 USEFUL rows (2 x 9 x Cin per pixel = the last layer's algorithmic FLOPs), not the 16 the tile issues
+        fused_flops = (2.0 * 9 * ms.planes(dom + 1)[0] * dom_flops / (18.0 * ms.planes(dom)[0] * ms.planes(dom)[1])) if fused_last else 0.0
         achieved = algorithmic * issued(dom) + (fused_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0)
         per_layer = []
         for l in range(n_layers):
@@ -507,11 +553,13 @@ def main():
             cin, cout = ms.planes(l)
             alg_bytes = (cin + cout) * 4 * flops_layer[l] / (18 * cin * cout)
             alg_tf = products * flops_layer[l] / (ms_l * 1e-3) / 1e12 if ms_l > 0 else None
+            # (the dominant layer's launch also carries the fused last layer's useful FLOPs: the same accounting as `roofline`)
+            fused_tf = fused_flops * nbands[l] / (ms_l * 1e-3) / 1e12 if (l == dom and ms_l > 0) else 0.0
             per_layer.append({"layer": l + 1, "kernel": ms.kernel_name(l, opts), "planes": "%d->%d" % (cin, cout),
                               "ms": round(ms_l, 4),
                               # what the MFMA pipe does: FLOPs the kernel issues / time, and its share of the peak
-                              "tflops": round(alg_tf * issued(l), 2) if ms_l > 0 else None,
-                              "frac_of_peak": round(alg_tf * issued(l) / peak, 4) if ms_l > 0 else None,
+                              "tflops": round(alg_tf * issued(l) + fused_tf, 2) if ms_l > 0 else None,
+                              "frac_of_peak": round((alg_tf * issued(l) + fused_tf) / peak, 4) if ms_l > 0 else None,
                               # SURVEY 8(d)'s algorithmic FLOPs over the same time
                               "algorithmic_tflops": round(alg_tf, 2) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
@@ -570,11 +618,16 @@ def main():
                                   " of the algorithmic multiplies: `achieved` / `frac` are the MFMA pipe's own rate (issued "
                                   "FLOPs / time / peak); `algorithmic_tflops` is SURVEY 8(d)'s FLOPs over the same time -- above the peak, i.e. faster than a "
                                   "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs") +
-                                 ("; the launch also issues the fused last layer's MFMAs (`fused_last_layer_flops_per_launch`, +3 %), counted in `achieved` but "
-                                  "not in the algorithmic figures of THIS layer" if fused_last else ""),
+                                 ("; the launch also carries the fused last layer (`fused_last_layer_flops_per_launch` = its 2 x 9 x Cin useful FLOPs per pixel, "
+                                  "+3 %; the 16-row tile it issues is not counted), in `achieved` and in layers[%d] alike, not in the algorithmic figures of THIS layer" % dom
+                                  if fused_last else ""),
                          "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,
             "output_finite": ok,
+            # the timed plane against the CPU oracle (checker): one border and one interior 48x48 patch, rtol 1e-4 + atol 1e-5 (north_star)
+            "parity_patch_max_rel_err": (float("%.4g" % parity[0]) if parity else None),
+            "parity_patch_within_gate": (parity[1] if parity else None),
+            "parity_patch_spots": ([list(p) for p in parity[2]] if parity else None),
         }
         if host:
             out["host_to_host"] = host

@@ -59,8 +59,9 @@ typedef struct w2xc_model w2xc_model;
 
 #define W2XC_KERNEL_AUTO    0   /* the fast kernel of each layer shape; for the fp32 layers with 32 / 64 / 128 planes in and out that is
                                  * W2XC_KERNEL_WINOGRAD4.  On a row-band view WITHOUT the wide halo below (w2xc_convert_rows_device /
-                                 * w2xc_convert_plane_rows) it runs the banding-invariant F(2x2) kernels instead (same tolerance,
-                                 * another rounding).  No environment switches: the choice is the caller's, per call.            */
+                                 * w2xc_convert_plane_rows) it is REFUSED with W2XC_ERR_ARG: the kernel (and with it the rounding)
+                                 * never changes silently with the view; such a caller passes the wide view or names a kernel.
+                                 * No environment switches: the choice is the caller's, per call.                            */
 #define W2XC_KERNEL_DIRECT  1   /* every layer: reference-ordered direct conv on VALU (bit-exact vs the oracle)             */
 #define W2XC_KERNEL_MFMA    2   /* mid layers: direct implicit GEMM, a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32
                                  * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
@@ -93,7 +94,10 @@ typedef struct w2xc_opts {
                                * W2XC_FUSION_OFF runs conv3x3_last as its own launch.  Results stay inside the fp32 gate either way
                                * (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
                                * (The 16-bit modes: environment W2XC_SPLIT_FUSE_FIRST / _LAST.) */
-} w2xc_opts;
+    int      host_units;      /* host-pointer entry points, test aid: cut the rows into this many units, round-robin over the selected
+                               * devices, so a one-GPU box runs the multi-device arithmetic; 0 = one unit per device              */
+    int      host_chunk_kb;   /* host-pointer entry points, test aid: maximum size of a staged output chunk in KiB; 0 = 8192     */
+} w2xc_opts;                  /* (verbose: bit 0 = the reference's progress lines, bit 1 = the host pipeline's phase timestamps on stderr) */
 
 #define W2XC_FUSION_AUTO 0
 #define W2XC_FUSION_OFF  1
@@ -172,7 +176,8 @@ int w2xc_convert_plane_device(w2xc_model *m, const float *d_in, size_t in_stride
  * Bands stitch BIT-identically with the whole-plane call when the view holds the WIDE halo,
  * [row_begin - 4 n_layers, row_end + 4 n_layers) clipped: the default F(4x4) mid-layer kernel works on 4x4 blocks
  * and needs every band region to end on a block row, four rows of halo per layer.  On a view with only the minimum
- * halo W2XC_KERNEL_AUTO runs the F(2x2) kernels for the call -- same tolerance, another rounding (1e-6 of the range). */
+ * halo W2XC_KERNEL_AUTO is refused (W2XC_ERR_ARG) -- the rounding never changes silently with the view; a named kernel
+ * (W2XC_KERNEL_WINOGRAD32 / _WINOGRAD / _MFMA / _DIRECT: banding-invariant there) runs on it.                        */
 int w2xc_convert_rows_device(w2xc_model *m, const float *d_view, size_t view_stride_bytes, int view_h,
                              int view_y0, int w, int plane_h, int row_begin, int row_end, float *d_out,
                              size_t out_stride_bytes, void *hip_stream, const w2xc_opts *opts);

@@ -215,11 +215,14 @@ def test_farm_unit_argument_contract(w2xc, noise1_layers):
     src = np.zeros((h, w), np.float32)
     ok_code = w2xc.OK if w2xc.device_count() > 0 else w2xc.ERR_HIP
 
-    def call(view_y0, view_h, nn2x, rb, re):
+    # the MINIMUM view (n halo rows) is a contract of the explicitly chosen F(2x2) kernels; W2XC_KERNEL_AUTO (the F(4x4) default) wants 4 n (below)
+    o32 = w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD32)
+
+    def call(view_y0, view_h, nn2x, rb, re, opts=o32):
         out = np.zeros((max(re - rb, 1), w << nn2x), np.float32)
         v = src[view_y0:view_y0 + view_h]
         return lib.w2xc_convert_plane_rows(ms.handle, v.ctypes.data, v.strides[0], view_y0, view_h, w, h, nn2x, rb, re,
-                                           out.ctypes.data, out.strides[0], None)
+                                           out.ctypes.data, out.strides[0], C.byref(opts) if opts is not None else None)
     for nn2x in (0, 1):
         H = h << nn2x
         for parts in (1, 2, 3, 7):
@@ -232,6 +235,13 @@ def test_farm_unit_argument_contract(w2xc, noise1_layers):
                     assert call(sy0 + 1, sy1 - sy0 - 1, nn2x, rb, re) == w2xc.ERR_ARG      # first halo row missing
                 if sy1 < h:
                     assert call(sy0, sy1 - sy0 - 1, nn2x, rb, re) == w2xc.ERR_ARG          # last halo row missing
+                # W2XC_KERNEL_AUTO (opts == NULL): the default F(4x4) kernel needs the WIDE halo (4 rows per layer) for banding-invariant results;
+                # on a narrower view it is refused -- never a silent change of kernel and rounding
+                wy0, wy1 = w2xc.shard_view(H, rb, re, 4 * n)
+                ws0, ws1 = wy0 >> nn2x, (wy1 + nn2x) >> nn2x
+                assert call(ws0, ws1 - ws0, nn2x, rb, re, None) == ok_code, (nn2x, parts, p)
+                if (ws0, ws1) != (sy0, sy1):
+                    assert call(sy0, sy1 - sy0, nn2x, rb, re, None) == w2xc.ERR_ARG and "4 halo rows per layer" in w2xc.last_error()
         assert call(0, h, nn2x, 10, 10) == w2xc.ERR_ARG                       # empty range
         assert call(0, h, nn2x, -1, 5) == w2xc.ERR_ARG
         assert call(0, h, nn2x, 0, H + 1) == w2xc.ERR_ARG

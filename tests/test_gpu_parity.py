@@ -226,26 +226,29 @@ def test_row_band_entry_point(gpu, scale_layers, parts, precision):
     assert e.value.code == gpu.ERR_ARG
 
 
-def test_row_bands_on_minimum_halo_views_run_the_f2x2_kernels(gpu, scale_layers):
-    """The default F(4x4) mid-layer kernel needs 4 n halo rows in a band's view for its banding-invariant geometry.  A caller
-    that passes the MINIMUM view ([ra - n, rb + n), what the entry point has always accepted) gets the F(2x2) kernels for that call
-    under W2XC_KERNEL_AUTO: the bands stitch bit-identically with the whole-plane run of THOSE kernels (w2xc_opts.kernel =
-    W2XC_KERNEL_WINOGRAD) and sit within the usual tolerance of the oracle and of the default whole-plane run."""
+def test_row_bands_on_minimum_halo_views(gpu, scale_layers):
+    """The default F(4x4) mid-layer kernel needs 4 n halo rows in a band's view for its banding-invariant geometry.  On the MINIMUM
+    view ([ra - n, rb + n)) W2XC_KERNEL_AUTO is REFUSED (W2XC_ERR_ARG: no silent change of kernel and rounding with the view's halo); a caller who
+    chooses the F(2x2) kernels explicitly (W2XC_KERNEL_WINOGRAD32) gets bands that stitch bit-identically with the whole-plane run of THOSE
+    kernels and sit within the usual tolerance of the oracle and of the default whole-plane run."""
     torch = pytest.importorskip("torch")
     ms = gpu._ModelSet.from_layers(scale_layers)
     h, w, parts = 150, 90, 3
     x = rand_plane(h, w, 13)
     out = torch.zeros((h, w), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream()
-    o = gpu.make_opts(device=0)
+    o = gpu.make_opts(device=0, kernel=gpu.KERNEL_WINOGRAD32)
     for p in range(parts):
         ra, rb = gpu.shard_rows(h, parts, p)
         y0, y1 = gpu.shard_view(h, ra, rb, ms.n_layers)
         view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
+        with pytest.raises(gpu.W2xcError) as e:
+            ms.convert_rows_device(view.data_ptr(), w * 4, y1 - y0, y0, w, h, ra, rb, out[ra:].data_ptr(), w * 4, stream=st.cuda_stream, opts=gpu.make_opts(device=0))
+        assert e.value.code == gpu.ERR_ARG and "halo rows" in str(e.value)
         ms.convert_rows_device(view.data_ptr(), w * 4, y1 - y0, y0, w, h, ra, rb, out[ra:].data_ptr(), w * 4, stream=st.cuda_stream, opts=o)
     st.synchronize()
     got = out.cpu().numpy()
-    assert np.array_equal(got, ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD)))
+    assert np.array_equal(got, ms.convert(x, opts=gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD32)))
     assert_close(got, orc.Oracle(scale_layers).convert(x, njob=8), "minimum-halo row bands")
     whole = ms.convert(x)
     assert np.abs(got - whole).max() <= 1e-5 * np.abs(whole).max()
@@ -661,26 +664,15 @@ def test_mfma2_race_screen(gpu, scale_layers, precision):
             assert torch.equal(y, ref), "run %d of %dx%d differs" % (it, h, w)
 
 
-def test_host_multi_band_path(gpu, scale_layers, tmp_path):
-    """the in-process multi-device path of w2xc_convert_plane / _nn2x (one host thread per band: upload band +
-    halo rows, convert, download band) -- on a 1-GPU box W2XC_HOST_BANDS=3 runs its three bands on the same
-    device.  Result must be bit-identical to the single-band run (read in a subprocess: env is read per call)."""
-    import subprocess, sys
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from tools import gen_model\n"
-        "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
-        "x = np.random.default_rng(4).random((101, 77), dtype=np.float32)\n"
-        "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert_nn2x(x)[:101, :77]]))\n" % ROOT)
-    outs = []
-    for bands in ("1", "3"):
-        f = str(tmp_path / ("o%s.npy" % bands))
-        env = dict(os.environ, W2XC_HOST_BANDS=bands)
-        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        outs.append(np.load(f))
-    assert np.array_equal(outs[0], outs[1])
+def test_host_multi_band_path(gpu, scale_layers):
+    """the in-process multi-device path of w2xc_convert_plane / _nn2x (one host thread per unit: upload rows +
+    halo rows, convert, download rows) -- on a 1-GPU box w2xc_opts.host_units = 3 runs its three units on the same
+    device.  Result must be bit-identical to the one-unit run."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = np.random.default_rng(4).random((101, 77), dtype=np.float32)
+    o3 = gpu.make_opts(host_units=3)
+    assert np.array_equal(ms.convert(x), ms.convert(x, opts=o3))
+    assert np.array_equal(ms.convert_nn2x(x), ms.convert_nn2x(x, opts=o3))
 
 
 def test_default_precision_from_environment(gpu, scale_layers, tmp_path):

@@ -2,6 +2,7 @@
 w2xc_convert_plane / _nn2x / _rows (pinned staging rings, H2D || layers || D2H + stitch, chunked last layer), the
 units of the multi-GPU farm, Model::filter's persistent buffers and device-resident chain, and bench.py's JSON lines
 at N = 1 and N = 2 (two ranks on one GPU over gloo).  Everything goes through the C ABI; the checker is the oracle."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -46,35 +47,33 @@ def device_result(gpu, ms, x, nn2x=False, **okw):
 def test_host_pipeline_bit_identical_to_resident_path(gpu, scale_layers, monkeypatch, chunk_kb, nn2x):
     """pageable planes through the staging rings, last layer in row chunks (16 KiB chunks: ~70 chunks, every slot of both
     rings reused many times; huge chunks: none) == the device-pointer entry point, bit for bit, and close to the oracle"""
-    if chunk_kb:
-        monkeypatch.setenv("W2XC_HOST_CHUNK_KB", chunk_kb)
+    ho = gpu.make_opts(host_chunk_kb=int(chunk_kb or 0))
     ms = gpu._ModelSet.from_layers(scale_layers)
     x = rand_plane(301, 423, 5)
     want = device_result(gpu, ms, x, nn2x)
-    got = ms.convert_nn2x(x) if nn2x else ms.convert(x)
+    got = ms.convert_nn2x(x, opts=ho) if nn2x else ms.convert(x, opts=ho)
     assert np.array_equal(got, want)
     ref = orc.Oracle(scale_layers).convert(np.repeat(np.repeat(x, 2, 0), 2, 1) if nn2x else x, njob=8)
     assert_close(got, ref, "host pipeline")
     # again on the same model: the persistent pipe (streams, buffers, rings) is reused, with a larger and a smaller plane
     for (h, w) in ((350, 500), (40, 64)):
         y = rand_plane(h, w, h)
-        assert np.array_equal(ms.convert(y), device_result(gpu, ms, y))
+        assert np.array_equal(ms.convert(y, opts=ho), device_result(gpu, ms, y))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x2", "bf16", "direct"])
 def test_host_pipeline_multi_band_and_every_last_layer_kernel(gpu, scale_layers, monkeypatch, precision):
     """several workspace bands (upload of band k+1 under band k) x chunked last layer, for every kernel the last layer can be:
     conv3x3_last, conv3x3_last_gather (16-bit modes: last layer fused into layer 6), conv3x3_direct"""
-    monkeypatch.setenv("W2XC_HOST_CHUNK_KB", "64")
     ms = gpu._ModelSet.from_layers(scale_layers)
     kw = {"kernel": gpu.KERNEL_DIRECT} if precision == "direct" else \
          {"precision": {"fp32": gpu.PRECISION_FP32, "fp16x2": gpu.PRECISION_FP16X2, "bf16": gpu.PRECISION_BF16}[precision]}
     x = rand_plane(333, 260, 8)
     one = device_result(gpu, ms, x, **kw)
     # one band through the host pipeline: chunked last layer (fp32 / direct) or layer 6 + gather chunked together (16-bit modes)
-    assert np.array_equal(ms.convert(x, opts=gpu.make_opts(**kw)), one)
-    assert np.array_equal(ms.convert_nn2x(x[:170, :131], opts=gpu.make_opts(**kw)), device_result(gpu, ms, x[:170, :131], True, **kw))
-    banded = ms.convert(x, opts=gpu.make_opts(band_rows=100, **kw))
+    assert np.array_equal(ms.convert(x, opts=gpu.make_opts(host_chunk_kb=64, **kw)), one)
+    assert np.array_equal(ms.convert_nn2x(x[:170, :131], opts=gpu.make_opts(host_chunk_kb=64, **kw)), device_result(gpu, ms, x[:170, :131], True, **kw))
+    banded = ms.convert(x, opts=gpu.make_opts(band_rows=100, host_chunk_kb=64, **kw))
     assert np.array_equal(banded, device_result(gpu, ms, x, band_rows=100, **kw))
     if precision in ("fp32", "direct"):
         assert np.array_equal(banded, one)      # banding never changes fp32 results (SURVEY I2)
@@ -133,26 +132,23 @@ def test_in_place_conversion_and_trim(gpu, scale_layers):
     o = gpu.make_opts(band_rows=64)
     assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, C.byref(o)) == 0
     assert np.array_equal(big[:400], want)
-    # in place with MORE THAN ONE unit (W2XC_HOST_BANDS: three units on this device, as three devices would run them): unit t's
+    # in place with MORE THAN ONE unit (w2xc_opts.host_units: three units on this device, as three devices would run them): unit t's
     # output rows are the halo source rows of its neighbours -- the source rows are snapshotted before the units fan out
-    os.environ["W2XC_HOST_BANDS"] = "3"
-    try:
-        assert np.array_equal(ms.convert(x), want)           # (the units stitch to the one-unit result)
-        buf = x.copy()
-        assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, buf.strides[0], 300, 400, buf.ctypes.data, buf.strides[0], 1, None) == 0
-        assert np.array_equal(buf, want), "in place, 3 units"
-        big = np.zeros((405, 300), np.float32)
-        big[5:] = x
-        assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, None) == 0
-        assert np.array_equal(big[:400], want), "overlapping, 3 units"
-        src = x[::2].copy()                                  # nearest-2x entry in place is impossible (sizes differ): overlapping allocation
-        both = np.zeros((500, 300), np.float32)              # source rows 0..99 of the view ARE output rows 300..399
-        both[300:, :150] = src[:, :150]
-        want2 = ms.convert_nn2x(np.ascontiguousarray(src[:, :150]))
-        assert lib.w2xc_convert_plane_nn2x(ms.handle, both[300:].ctypes.data, both.strides[0], 150, 200, both.ctypes.data, both.strides[0], None) == 0
-        assert np.array_equal(both[:400], want2), "nn2x into an overlapping allocation, 3 units"
-    finally:
-        del os.environ["W2XC_HOST_BANDS"]
+    o3 = gpu.make_opts(host_units=3)
+    assert np.array_equal(ms.convert(x, opts=o3), want)           # (the units stitch to the one-unit result)
+    buf = x.copy()
+    assert lib.w2xc_convert_plane(ms.handle, buf.ctypes.data, buf.strides[0], 300, 400, buf.ctypes.data, buf.strides[0], 1, C.byref(o3)) == 0
+    assert np.array_equal(buf, want), "in place, 3 units"
+    big = np.zeros((405, 300), np.float32)
+    big[5:] = x
+    assert lib.w2xc_convert_plane(ms.handle, big[5:].ctypes.data, big.strides[0], 300, 400, big.ctypes.data, big.strides[0], 1, C.byref(o3)) == 0
+    assert np.array_equal(big[:400], want), "overlapping, 3 units"
+    src = x[::2].copy()                                  # nearest-2x entry in place is impossible (sizes differ): overlapping allocation
+    both = np.zeros((500, 300), np.float32)              # source rows 0..99 of the view ARE output rows 300..399
+    both[300:, :150] = src[:, :150]
+    want2 = ms.convert_nn2x(np.ascontiguousarray(src[:, :150]))
+    assert lib.w2xc_convert_plane_nn2x(ms.handle, both[300:].ctypes.data, both.strides[0], 150, 200, both.ctypes.data, both.strides[0], C.byref(o3)) == 0
+    assert np.array_equal(both[:400], want2), "nn2x into an overlapping allocation, 3 units"
     ms.trim()
     assert np.array_equal(ms.convert(x), want)
     ms.trim()
@@ -186,7 +182,7 @@ def test_farm_units_from_host_memory(gpu, scale_layers, parts, nn2x):
 
 def test_device_mask_over_every_visible_device(gpu, scale_layers):
     """w2xc_convert_plane with device_mask = all devices (one host thread + pipe per device, contiguous row shares, host
-    gather); on a 1-GPU box this is the single-device path -- the N-device arithmetic is exercised by W2XC_HOST_BANDS
+    gather); on a 1-GPU box this is the single-device path -- the N-device arithmetic is exercised by w2xc_opts.host_units
     (test_host_multi_band_path) and by the 2-rank bench launch below."""
     ms = gpu._ModelSet.from_layers(scale_layers)
     nd = gpu.device_count()
@@ -288,6 +284,30 @@ def test_filter_device_nhwc_chain(gpu):
     assert e.value.code == gpu.ERR_PLANES
 
 
+@pytest.mark.parametrize("w", [70, 69, 71, 72])
+def test_filter_device_roi_of_a_wider_tensor_keeps_the_neighbours(gpu, w):
+    """w2xc_layer_filter_device on an ROI: the output planes are a w-column sub-view of wider rows (row stride a multiple of 4, aligned base --
+    everything conv3x3_wino4's planar epilogue could store straight into).  Its stores are whole 16-byte pixel quads, so with w % 4 != 0 the last
+    quad of a row reaches into columns [w, roundup4(w)): those belong to the caller and must come back untouched (the engine takes the direct
+    path only when w % 4 == 0), and the ROI itself equals the contiguous call bit for bit."""
+    import torch
+    layers = small_layers([64, 64], 17)
+    ms = gpu._ModelSet.from_layers(layers)
+    assert ms.kernel_name(0) == "conv3x3_wino4"
+    h, W = 37, 96
+    x = np.random.default_rng(5).random((64, h, w), dtype=np.float32)
+    want = ms.filter(0, x)
+    st = torch.cuda.current_stream()
+    o = gpu.make_opts(device=0)
+    d_in = torch.from_numpy(x).cuda()
+    wide = torch.full((64, h, W), -7.25, device="cuda")
+    ms.filter_device(0, 64, d_in.data_ptr(), (h * w, w, 1), w, h, wide.data_ptr(), (h * W, W, 1), stream=st.cuda_stream, opts=o)
+    st.synchronize()
+    got = wide.cpu().numpy()
+    assert np.array_equal(got[:, :, :w], want)
+    assert np.all(got[:, :, w:] == np.float32(-7.25)), "columns outside the ROI were written"
+
+
 # ---- bench.py: the lines the driver records ------------------------------------------------------------------------------
 def run_bench(args, env=None, nproc=1, timeout=600):
     e = dict(os.environ, **(env or {}))
@@ -323,6 +343,8 @@ def test_bench_line_single_gpu(gpu):
     assert all(0 < l["frac_of_peak"] < 1 for l in j["layers"] if l["frac_of_peak"] is not None) and sum(l["frac_of_peak"] is None for l in j["layers"]) <= 1
     assert ("conv3x3_wino" in r["kernel"] or "conv3x3_mfma" in r["kernel"]) and "128->128" in r["kernel"]
     assert len(j["layers"]) == 7 and "workload" in j["config"]
+    assert abs(r["frac"] - j["layers"][5]["frac_of_peak"]) < 2e-4   # one accounting for the dominant launch in both places
+    assert j["parity_patch_max_rel_err"] is None   # (--no-cpu-baseline: the oracle is not touched)
 
 
 def test_bench_rccl_process_group_one_rank(gpu):
@@ -357,6 +379,25 @@ def test_bench_two_ranks_shard_one_plane_on_the_hip_path(gpu, tmp_path):
     layers = gen_model.synth_layers(seed=gen_model.SEEDS["scale2.0x"])
     want = orc.Oracle(layers).convert(nn2x(synth_luma(2, 96, 128)), njob=8)
     assert_close(got, want, "2-rank sharded plane")
+
+
+def test_bench_plain_invocation_gpus2(gpu):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the shape of the driver's N = 1 command with another N): bench.py re-executes
+    itself under the launcher, one rank per GPU -- on this one-GPU box the two ranks share the device, so it picks gloo for the barrier by
+    itself -- and prints the one N = 2 line.  A first multi-GPU run cannot fail for a launcher reason."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "W2XC_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--height", "96", "--width", "128", "--steps", "2", "--warmup", "1", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == "strong" and len(j["rank_ms_per_step"]) == 2 and j["value"] > 0
+    import torch
+    assert j["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert j["host_to_host"]["max_abs_diff_vs_resident_output"] == 0.0 and j["output_finite"]
+    # the timed plane against the oracle, in the line itself
+    assert j["parity_patch_within_gate"] is True and 0 <= j["parity_patch_max_rel_err"] <= 1e-4
 
 
 def test_bench_eight_ranks_shard_one_plane_bit_identical_to_one_rank(gpu, tmp_path):

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
-"""One 1080p -> 2160p host -> host call with W2XC_HOST_TRACE=1: the phase timestamps of the unit (stderr), pageable and pinned planes."""
+"""One 1080p -> 2160p host -> host call with w2xc_opts.verbose = 2: the phase timestamps of the unit (stderr), pageable and pinned planes."""
 import os, sys, time
-os.environ["W2XC_HOST_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as g
@@ -12,8 +11,9 @@ y = np.random.default_rng(1).random((1080, 1920), dtype=np.float32)
 out = np.zeros((2160, 3840), np.float32)
 lib = w.lib()
 import ctypes as C
+opts = w.make_opts(verbose=2)
 def call(src, dst):
-    rc = lib.w2xc_convert_plane_nn2x(ms.handle, src.ctypes.data, src.strides[0], 1920, 1080, dst.ctypes.data, dst.strides[0], None)
+    rc = lib.w2xc_convert_plane_nn2x(ms.handle, src.ctypes.data, src.strides[0], 1920, 1080, dst.ctypes.data, dst.strides[0], C.byref(opts))
     assert rc == 0
 for _ in range(3): call(y, out)
 for _ in range(4):

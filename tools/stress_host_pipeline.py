@@ -25,11 +25,11 @@ for it in range(a.iters):
     nn2x = bool(rng.integers(0, 2))
     prec = [w2xc.PRECISION_FP32, w2xc.PRECISION_FP32, w2xc.PRECISION_FP16X2, w2xc.PRECISION_BF16][int(rng.integers(0, 4))]
     band = [0, 0, 37, 128, 200][int(rng.integers(0, 5))]
-    os.environ["W2XC_HOST_CHUNK_KB"] = str([16, 64, 512, 8192][int(rng.integers(0, 4))])
+    chunk = [16, 64, 512, 8192][int(rng.integers(0, 4))]
     w2xc.lib().w2xc_set_jobs(int(rng.integers(1, 9)))
     x = rng.random((h, w), dtype=np.float32)
     kw = dict(precision=prec, band_rows=band)
-    got = ms.convert_nn2x(x, opts=w2xc.make_opts(**kw)) if nn2x else ms.convert(x, opts=w2xc.make_opts(**kw))
+    got = ms.convert_nn2x(x, opts=w2xc.make_opts(host_chunk_kb=chunk, **kw)) if nn2x else ms.convert(x, opts=w2xc.make_opts(host_chunk_kb=chunk, **kw))
     up = 2 if nn2x else 1
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty((h * up, w * up), dtype=torch.float32, device="cuda")
@@ -42,6 +42,6 @@ for it in range(a.iters):
     want = d_out.cpu().numpy()
     if not np.array_equal(got, want):
         bad += 1
-        print("MISMATCH it=%d %dx%d nn2x=%d prec=%d band=%d chunk=%s: max abs diff %g" % (it, h, w, nn2x, prec, band, os.environ["W2XC_HOST_CHUNK_KB"], np.abs(got - want).max()), flush=True)
+        print("MISMATCH it=%d %dx%d nn2x=%d prec=%d band=%d chunk=%s: max abs diff %g" % (it, h, w, nn2x, prec, band, chunk, np.abs(got - want).max()), flush=True)
 print("stress_host_pipeline: %d iterations, %d mismatches" % (a.iters, bad))
 sys.exit(1 if bad else 0)

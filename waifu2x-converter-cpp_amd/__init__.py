@@ -43,7 +43,8 @@ class Opts(C.Structure):
     """struct w2xc_opts (include/w2xc_hip.h)."""
     _fields_ = [("struct_size", C.c_int), ("precision", C.c_int), ("kernel", C.c_int), ("device", C.c_int),
                 ("device_mask", C.c_uint), ("band_rows", C.c_int), ("workspace_mb", C.c_int),
-                ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int), ("fusion", C.c_int)]
+                ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int), ("fusion", C.c_int),
+                ("host_units", C.c_int), ("host_chunk_kb", C.c_int)]
 
 
 def _load():
@@ -474,8 +475,8 @@ def shard_view(plane_h, row_begin, row_end, n_layers):
     """Input rows [y0, y1) a shard needs: its rows plus an n_layers halo, clipped to the plane
     (the 2*nModel overlap of the reference's block split, convertRoutine.cpp:100-131).  This is the MINIMUM the row entry points accept;
     a shard that is to stitch BIT-identically with the whole-plane call passes the wide halo -- shard_view(h, ra, rb, 4 * n_layers) -- which the
-    default F(4x4) mid-layer kernel needs for its banding-invariant geometry (on the minimum view W2XC_KERNEL_AUTO runs the F(2x2) kernels:
-    same tolerance, another rounding)."""
+    default F(4x4) mid-layer kernel needs for its banding-invariant geometry (on the minimum view W2XC_KERNEL_AUTO is refused with
+    ERR_ARG; name a kernel -- KERNEL_WINOGRAD32 is banding-invariant there -- to use it)."""
     return max(0, row_begin - n_layers), min(plane_h, row_end + n_layers)
 
 

@@ -418,8 +418,8 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 //   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD (round 3; 64 / 128 output planes)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
-// _WINOGRAD32 / _WINOGRAD4); W2XC_KERNEL_AUTO takes the process default: Winograd unless W2XC_WINOGRAD=0 -- conv3x3_wino4 (F(4x4,3x3)) where it applies
-// (>= 64 output planes) unless W2XC_WINO_KERNEL=16 (conv3x3_wino16) or =32 (conv3x3_wino).
+// _WINOGRAD32 / _WINOGRAD4); W2XC_KERNEL_AUTO = W2XC_KERNEL_WINOGRAD4: conv3x3_wino4 (F(4x4,3x3)) where it applies (>= 64 output planes),
+// conv3x3_wino for the rest.  No environment variable takes part in the choice.
 //   MID_WINO4   conv3x3_wino4:  Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (round 3, the default: 1.78x fewer multiplies again, ~1.3x the rounding error of
 //               F(2x2); needs the four-rows-per-layer band geometry of run_rows to stay banding-invariant)
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2, MID_WINO4 = 3 };
@@ -478,7 +478,7 @@ bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o)   // layout 
 
 // fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
 // the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
-// w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on unless W2XC_FUSE_LAST_FP32=0.
+// w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on.
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
 {
     const int n = (int)m->layers.size();
@@ -602,7 +602,7 @@ struct BandHooks {
 // last layer written planar `out_cs` floats apart.  n_in == 1 && out_cs == 0 is convertWithModels proper,
 // which returns only outputPlanes[0] (convertRoutine.cpp:78).
 // plane_h = rows of the whole plane (the units of vh / vy0 / ra / rb), 0 = unknown.  With it, and a view that holds 4 n halo rows, the
-// layers run on the banding-invariant geometry conv3x3_wino4 needs (below); without, W2XC_KERNEL_AUTO falls back to the F(2x2) kernels.
+// layers run on the banding-invariant geometry conv3x3_wino4 needs (below); without, W2XC_KERNEL_AUTO is refused (W2XC_ERR_ARG).
 int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,
              float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o_in, int up = 0, int n_in = 1,
              long long in_cs = 0, long long out_cs = 0, const BandHooks *hk = nullptr, int plane_h = 0)
@@ -619,7 +619,10 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
     if (uses_wino4(m, o)) {
         const int hs = 4 * n;
         if (plane_h > 0 && vy0 <= std::max(0, ra - hs) && vy0 + vh >= std::min(plane_h, rb + hs)) HL = 4;
-        else if (o.kernel == W2XC_KERNEL_AUTO) o.kernel = W2XC_KERNEL_WINOGRAD;   // a view with n halo rows only: the banding-invariant F(2x2) kernels
+        else if (o.kernel == W2XC_KERNEL_AUTO)   // a view with n halo rows only: no silent change of kernel (and rounding) -- the caller decides
+            return fail(W2XC_ERR_ARG, "row-band view [%d,%d) of rows [%d,%d): the default F(4x4) kernel needs %d halo rows (4 per layer) for banding-invariant results; "
+                                      "pass the wide view or choose w2xc_opts.kernel explicitly (W2XC_KERNEL_WINOGRAD32: F(2x2), banding-invariant on the minimum view)",
+                        vy0, vy0 + vh, ra, rb, hs);
         // (an explicit W2XC_KERNEL_WINOGRAD4 on a narrow view runs as asked: results then depend on the banding at rounding level)
     }
     auto region = [&](int k, int y0, int y1, int &T, int &B) {   // plane rows [T, B) layer k computes for the band [y0, y1)
@@ -717,7 +720,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         int src_h = vh, src_w = w;
         int Tprev = vy0;   // first plane row held by the buffer layer k reads (the source view for k = 1)
         for (int k = 1; k <= n; k++) {
-            if (o.verbose) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
+            if (o.verbose & 1) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
             const HostLayer &hl = m->layers[k - 1];
             W2xcConvDesc d;
             memset(&d, 0, sizeof d);
@@ -795,8 +798,10 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             // band's download behind.  So layer n-1 and the gather run TOGETHER in row chunks (quarters of the band, whole 16-row
             // tiles): chunk j's rows leave for the host under layer n-1 of chunk j+1.  The producer chunks tile the G rows without
             // overlap (chunk j computes G rows up to r1 + 2, the next one continues there): no recompute.
+            // (not conv3x3_wino4 as the producer -- an explicit W2XC_KERNEL_WINOGRAD4 on a narrow view: these chunks start at g_done = r1 + 2, not on a block
+            //  row, so its F(4x4) block grid would shift from chunk to chunk; the tail path below cuts it on whole 16-row tiles)
             if (hk && HL == 1 && k == n - 1 && n >= 3 && (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_MFMA) && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
-                hk->output_ready && (y1 - y0) >= 128) {   // (HL = 4: the producer's rows do not start one above the band's: the unchunked path)
+                !is_wino4_layer(m, k - 1, o) && hk->output_ready && (y1 - y0) >= 128) {   // (HL = 4: the producer's rows do not start one above the band's: the unchunked path)
                 if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
                 const int R = y1 - y0;
                 const int cr = std::max(64, ((R / 4) + 15) & ~15);
@@ -1421,12 +1426,8 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     const bool in_pinned = host_range_pinned((const char *)in + (size_t)sy0 * in_stride, (size_t)(svh - 1) * in_stride + in_row);
     const bool out_pinned = host_range_pinned((const char *)out + (size_t)ra * out_stride, (size_t)(rb - ra - 1) * out_stride + out_row);
     // staging granularity, whole rows: input slices of ~2 MiB; output chunks of at most ~8 MiB tapering to 1/16 of that
-    // (multiples of the 8-row tiles of the last-layer kernels).  W2XC_HOST_CHUNK_KB overrides the maximum (test aid).
-    const size_t chunk_max = [] {
-        const char *e = getenv("W2XC_HOST_CHUNK_KB");
-        const long v = e ? atol(e) : 0;
-        return v > 0 ? (size_t)v << 10 : (size_t)8 << 20;
-    }();
+    // (multiples of the 8-row tiles of the last-layer kernels).  w2xc_opts.host_chunk_kb overrides the maximum (test aid).
+    const size_t chunk_max = o.host_chunk_kb > 0 ? (size_t)o.host_chunk_kb << 10 : (size_t)8 << 20;
     const int in_chunk_rows = (int)std::max<size_t>(1, std::min<size_t>(chunk_max, (size_t)2 << 20) / in_row);
     const int out_chunk_rows = (int)std::max<size_t>(8, (chunk_max / out_row) & ~(size_t)7);
     const int out_chunk_min = (int)std::max<size_t>(8, (chunk_max / 16 / out_row) & ~(size_t)7);
@@ -1583,7 +1584,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         return W2XC_OK;
     };
 
-    static const bool trace = getenv("W2XC_HOST_TRACE") != nullptr;   // (debug aid) phase timestamps of one unit on stderr
+    const bool trace = (o.verbose & 2) != 0;   // (debug aid) phase timestamps of one unit on stderr
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk, H);
@@ -1633,7 +1634,10 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         const int h4 = 4 * hs;
         const int need0 = std::max(0, row_begin - h4) >> up, need1 = (std::min(H, row_end + h4) + up) >> up;
         if (in_row0 <= need0 && in_row0 + in_rows >= need1) hs = h4;
-        else if (o.kernel == W2XC_KERNEL_AUTO) o.kernel = W2XC_KERNEL_WINOGRAD;
+        else if (o.kernel == W2XC_KERNEL_AUTO)   // (as run_rows: no silent change of kernel and rounding with the view's halo)
+            return fail(W2XC_ERR_ARG, "source rows [%d,%d) hold the minimum halo only: the default F(4x4) kernel needs rows [%d,%d) (4 halo rows per layer) for "
+                                      "banding-invariant results; pass them or choose w2xc_opts.kernel explicitly (W2XC_KERNEL_WINOGRAD32: F(2x2))",
+                        in_row0, in_row0 + in_rows, need0, need1);
     }
     const int ndev_all = w2xc_device_count();
     if (ndev_all <= 0) return fail(W2XC_ERR_HIP, "no HIP device available (libw2xc_hip has no CPU fallback)");
@@ -1642,10 +1646,10 @@ int convert_plane_host(w2xc_model *m, const float *in, size_t in_stride_bytes, i
         if (o.device_mask == 0 || (o.device_mask >> d) & 1u) devs.push_back(d);
     if (devs.empty()) return fail(W2XC_ERR_ARG, "device_mask 0x%x selects no available device (%d present)", o.device_mask, ndev_all);
     int nd = (int)devs.size();
-    // W2XC_HOST_BANDS=<k> (test aid): cut the rows into k units, round-robin over the selected devices,
+    // w2xc_opts.host_units = k (test aid): cut the rows into k units, round-robin over the selected devices,
     // so the multi-device arithmetic below can be exercised on a single-GPU box
-    if (const char *e = getenv("W2XC_HOST_BANDS")) {
-        const int k = atoi(e);
+    {
+        const int k = o.host_units;
         if (k > nd) {
             const size_t have = devs.size();
             for (int i = (int)have; i < k && i < 64; i++) devs.push_back(devs[i % have]);
@@ -1835,7 +1839,9 @@ int filter_on_device(w2xc_model *m, DevCtx *c, int layer, const float *in, long 
         d.in_h = h + 2; d.in_w = w + 2;
         d.off_y = d.off_x = 0;
         const long long ors = ((long long)w + 31) & ~31ll;
-        const bool planar_direct = out_ps == 1 && (out_rs & 3) == 0 && (out_cs & 3) == 0 && (((size_t)out) & 15) == 0 && out_rs >= (((long long)w + 3) & ~3ll);
+        // (the planar epilogue stores whole 16-byte pixel quads: straight into the caller's planes only when w is a multiple of 4 -- with a ragged
+        //  last quad it would write up to three floats past column w - 1 of every row, which in a sub-view of a wider tensor are the caller's)
+        const bool planar_direct = out_ps == 1 && (w & 3) == 0 && (out_rs & 3) == 0 && (out_cs & 3) == 0 && (((size_t)out) & 15) == 0 && out_rs >= (long long)w;
         const bool nhwc_direct = nhwc_ok(out, out_cs, out_rs, out_ps, hl.nout);
         if (planar_direct || nhwc_direct) {
             d.out = out; d.out_rs = out_rs; d.out_ps = out_ps; d.out_cs = out_cs;

@@ -569,86 +569,6 @@ __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv3x3_last_planar: the same layer on PLANAR input (what conv3x3_wino4p writes).  A lane's 16-byte load is four consecutive
-// pixels of ONE channel, so a group of 16 lanes x 4 pixels = 64 pixels of the halo tile (rows of 36 pixels = 9 quads) is contracted
-// by four MFMAs per (channel group, j): MFMA b takes element b of every lane's quad -- M row i = pixel 4 i + b of the group.
-// Same packed weights as conv3x3_last.  off_x = 0 and 16-byte aligned rows (the engine's planar workspaces).
-// ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) conv3x3_last_planar(W2xcConvDesc d, int tiles_x, int ntiles)
-{
-    constexpr int ROWS = 8, HWQ = 9, HW = 4 * HWQ, HH = ROWS + 2, NQUAD = HH * HWQ;   // 90 quads = 360 pixel slots
-    constexpr int NGRP = (NQUAD + 15) / 16;                                            // 6 groups of 16 quads
-    constexpr int N = 9 * COUT, NB16 = (N + 15) / 16;
-    constexpr int GS = N | 1;                  // odd LDS row stride
-    constexpr int S4 = CIN / 16;
-    __shared__ float G[NGRP * 64 * GS];
-
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kk = lane >> 4, i = lane & 15;
-    const int xq_last = (d.in_w - 1) & ~3;
-
-    for (int grp = wave; grp < NGRP; grp += 4) {
-        int quad = grp * 16 + i;
-        quad = quad < NQUAD ? quad : NQUAD - 1;
-        const int py = quad / HWQ, pq = quad - py * HWQ;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
-        int gx = ox0 + 4 * pq + d.off_x;
-        gx = gx < xq_last ? gx : xq_last;       // (quads past the row end re-read its last one: they only feed outputs >= out_w)
-        const float *src = d.in + (long long)gy * d.in_rs + gx;
-        f32x4 acc[4][NB16];
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int nb = 0; nb < NB16; nb++) acc[b][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s4 = 0; s4 < S4; s4++) {
-            f32x4 av[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const f32x4 *>(src + (long long)(16 * s4 + 4 * kk + j) * d.in_cs);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int nb = 0; nb < NB16; nb++) {
-                    const float bw = d.wpk[((s4 * 4 + j) * NB16 + nb) * 64 + lane];
-#pragma unroll
-                    for (int b = 0; b < 4; b++) acc[b][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][b], bw, acc[b][nb], 0, 0, 0);
-                }
-        }
-        // C/D map of the 16x16 MFMA: column = lane & 15 (n), row = 4 (lane >> 4) + r = quad of the group; element b of it = pixel slot 4 quad + b
-#pragma unroll
-        for (int nb = 0; nb < NB16; nb++) {
-            const int n = nb * 16 + i;
-            if (n < N) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) G[((grp * 16 + kk * 4 + r) * 4 + b) * GS + n] = acc[b][nb][r];
-            }
-        }
-    }
-    __syncthreads();
-
-    for (int p = threadIdx.x; p < ROWS * 32; p += 256) {
-        const int py = p >> 5, px = p & 31;
-        const int y = oy0 + py, x = ox0 + px;
-        if (y >= d.out_h || x >= d.out_w) continue;
-#pragma unroll
-        for (int o = 0; o < COUT; o++) {
-            float v = 0.0f;
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++)
-                v += G[((py + tap / 3) * HW + px + tap % 3) * GS + tap * COUT + o];
-            d.out[(long long)o * d.out_cs + (long long)y * d.out_rs + (long long)x * d.out_ps] = leaky(v + d.bias[o]);
-        }
-    }
-}
-
 // replicate-padded planar copy: dst plane c (ph x pw pixels, row stride d_rs, plane stride d_cs) = src(clamp(y - pad), clamp(x - pad)) -- the
 // BORDER_REPLICATE of Model::filter (modelHandler.cpp:141-142) made explicit for the kernels that run a valid conv on aligned planar tiles
 __global__ void __launch_bounds__(256) pad_planar_kernel(const float *src, long long s_rs, long long s_ps, long long s_cs, float *dst, long long d_rs,
@@ -786,7 +706,6 @@ static hipError_t launch_mfma2(const W2xcConvDesc &d, hipStream_t stream)
     return hipGetLastError();
 }
 
-// W2XC_MFMA_V2 (tuning aid): unset = default tilings, 1 = conv3x3_mfma2 with 4 waves everywhere, 3 = 8 waves where possible
 template <typename KernelT>
 static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
 {
@@ -851,19 +770,6 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         case 3032: return launch_first(conv3x3_first<3, 1>, d, stream);
         case 3064: return launch_first(conv3x3_first<3, 2>, d, stream);
         case 3128: return launch_first(conv3x3_first<3, 4>, d, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    if (kind == W2XC_K_LAST && d.in_ps == 1 && d.in_cs != 1) {   // planar in
-        if ((d.in_rs & 3) != 0 || (d.in_cs & 3) != 0 || (((size_t)d.in) & 15) != 0 || (d.off_x & 3) != 0 || d.off_x < 0 || d.in_rs < ((d.in_w + 3) & ~3))
-            return hipErrorInvalidValue;
-        switch (d.cin * 1000 + d.cout) {
-        case 32001:  return launch_tiled8(conv3x3_last_planar<32, 1>, d, stream);
-        case 64001:  return launch_tiled8(conv3x3_last_planar<64, 1>, d, stream);
-        case 128001: return launch_tiled8(conv3x3_last_planar<128, 1>, d, stream);
-        case 32003:  return launch_tiled8(conv3x3_last_planar<32, 3>, d, stream);
-        case 64003:  return launch_tiled8(conv3x3_last_planar<64, 3>, d, stream);
-        case 128003: return launch_tiled8(conv3x3_last_planar<128, 3>, d, stream);
         default: return hipErrorInvalidValue;
         }
     }
