@@ -619,7 +619,7 @@ def main():
                                   "FLOPs / time / peak); `algorithmic_tflops` is SURVEY 8(d)'s FLOPs over the same time -- above the peak, i.e. faster than a "
                                   "direct convolution can run on this MFMA" if issued(dom) < 1 else "direct convolution: issued = algorithmic FLOPs") +
                                  ("; the launch also carries the fused last layer (`fused_last_layer_flops_per_launch` = its 2 x 9 x Cin useful FLOPs per pixel, "
-                                  "+3 %; the 16-row tile it issues is not counted), in `achieved` and in layers[%d] alike, not in the algorithmic figures of THIS layer" % dom
+                                  "+3 %%; the 16-row tile it issues is not counted), in `achieved` and in layers[%d] alike, not in the algorithmic figures of THIS layer" % dom
                                   if fused_last else ""),
                          "timing": "hipEvents on the launch stream around every launch, second pass of the same %d steps" % args.steps},
             "layers": per_layer,

@@ -1435,11 +1435,18 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                       out_pinned ? 0 : (size_t)out_chunk_rows * out_row);
     if (rc) return rc;
 
+    const bool trace = (o.verbose & 2) != 0;   // (debug aid) phase timestamps of one unit on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    double t_in_done = -1, t_first_out = -1;
+
     // ---- input side: source rows [0, svh) of this unit's view, uploaded in order up to a high-water mark ----
     int uploaded = 0;        // view rows already queued on s_h2d
     long in_seq = 0;         // staging slots used so far
     auto upload_to = [&](int s_end) -> int {
         s_end = std::min(s_end, svh);
+        struct Stamp { double &t; bool on; int &up; int all; std::function<double()> now; ~Stamp() { if (on && t < 0 && up >= all) t = now(); } }
+            stamp{t_in_done, trace, uploaded, svh, [&] { return ms_since(t0); }};
         while (uploaded < s_end) {
             if (in_pinned) {   // DMA straight from the caller's plane
                 const int rows = s_end - uploaded;
@@ -1553,6 +1560,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         return W2XC_OK;
     };
     hk.output_ready = [&](int r0, int r1) -> int {
+        if (trace && t_first_out < 0) t_first_out = ms_since(t0);
         HIP_TRY(hipEventRecord(p.ev_chunk, p.s_compute));
         HIP_TRY(hipStreamWaitEvent(p.s_d2h, p.ev_chunk, 0));
         if (out_pinned) {
@@ -1584,17 +1592,14 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         return W2XC_OK;
     };
 
-    const bool trace = (o.verbose & 2) != 0;   // (debug aid) phase timestamps of one unit on stderr
-    const auto t0 = std::chrono::steady_clock::now();
-    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk, H);
     const double t_enq = ms_since(t0);
     double t_comp = 0;
     if (trace) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
     std::string err = g_last_error;
     finish_drainer();
-    if (trace) fprintf(stderr, "[w2xc host] device %d (cpu node %d%s) rows %d..%d: enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s, %d copy threads)\n",
-                       dev, node_guard.node, node_guard.bound ? ", threads bound" : "", ra, rb, t_enq, t_comp,
+    if (trace) fprintf(stderr, "[w2xc host] device %d (cpu node %d%s) rows %d..%d: input queued %.3f ms, first output chunk enqueued %.3f ms, enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s, %d copy threads)\n",
+                       dev, node_guard.node, node_guard.bound ? ", threads bound" : "", ra, rb, t_in_done, t_first_out, t_enq, t_comp,
                        ms_since(t0), in_pinned ? "pinned" : "pageable", out_pinned ? "pinned" : "pageable", copy_threads);
     // leave nothing in flight, whatever happened: the pipe and the caller's planes are reused by the next call
     hipError_t e1 = hipStreamSynchronize(p.s_h2d), e2 = hipStreamSynchronize(p.s_compute), e3 = hipStreamSynchronize(p.s_d2h);
