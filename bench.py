@@ -32,7 +32,7 @@ Extra objects on the JSON line:
                in a second pass of the same K steps right after the timed region (so the events are not inside
                `value`'s region; `ms_per_step_profiled` shows they cost nothing), vs the 157.3 TFLOP/s fp32 MFMA peak.
                That layer runs a Winograd kernel (conv3x3_wino4, F(4x4,3x3): 36 instead of 144 multiplies per plane pair and
-               4x4 block; conv3x3_wino16 / conv3x3_wino, F(2x2,3x3): 16 instead of 36 per 2x2 block; all fp32).  `achieved` / `frac`
+               4x4 block; conv3x3_wino, F(2x2,3x3): 16 instead of 36 per 2x2 block; all fp32).  `achieved` / `frac`
                are what the MFMA pipe really does: the FLOPs the kernel ISSUES (1/4 resp. 16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
                reproducible from profiles/r4_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
                time) is carried beside it as `algorithmic_tflops` / `algorithmic_speedup_vs_direct_roofline` (> 1 means
@@ -445,14 +445,14 @@ def main():
                     other[name] = {"ms_per_step": round(t, 3), "Mpix_s": round(in_h * in_w / t / 1e3, 2),
                                    "max_abs_diff_vs_fp32_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng))}
                 extras["other_precisions"] = other
-                # the F(2x2,3x3) kernel of round 3's first half on the same plane (w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD: conv3x3_wino16, last layer fused)
-                o4 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, band_rows=args.band_rows, kernel=w2xc.KERNEL_WINOGRAD)
+                # the F(2x2,3x3) kernel on the same plane (w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD32: conv3x3_wino on every mid layer, last layer as its own launch)
+                o4 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, band_rows=args.band_rows, kernel=w2xc.KERNEL_WINOGRAD32)
                 run4 = lambda: ms.convert_device(d_in.data_ptr(), W * 4, W, H, d_out.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o4)
                 t4 = time_steps(run4, 5, 2) / 5 * 1e3
-                extras["other_kernels"] = {"winograd_f2x2 (conv3x3_wino16, w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD)": {
+                extras["other_kernels"] = {"winograd_f2x2 (conv3x3_wino, w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD32)": {
                     "ms_per_step": round(t4, 3), "Mpix_s": round(in_h * in_w / t4 / 1e3, 2),
                     "max_abs_diff_vs_default_path_over_range": float("%.3g" % ((d_out - ref).abs().max().item() / rng)),
-                    "note": "4 multiplies per output where the default F(4x4,3x3) kernel does 2.25; the last layer rides in its epilogue"}}
+                    "note": "4 multiplies per output where the default F(4x4,3x3) kernel does 2.25"}}
                 # BASELINE.json configs[2] on ONE GPU (what N > 1 shards): 8192x8192 frame, host -> host and resident
                 del ref
                 yb = synth_luma(seed=2, h=8192, w=8192)

@@ -65,8 +65,10 @@ typedef struct w2xc_model w2xc_model;
 #define W2XC_KERNEL_DIRECT  1   /* every layer: reference-ordered direct conv on VALU (bit-exact vs the oracle)             */
 #define W2XC_KERNEL_MFMA    2   /* mid layers: direct implicit GEMM, a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32
                                  * (conv3x3_mfma2) -- the closest MFMA analogue of modelHandler.cpp:134-145                */
-#define W2XC_KERNEL_WINOGRAD 3  /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (conv3x3_wino16), fp32 throughout */
-#define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: the round-2 Winograd kernel on v_mfma_f32_32x32x2_f32 (conv3x3_wino)        */
+#define W2XC_KERNEL_WINOGRAD 3  /* = W2XC_KERNEL_WINOGRAD32 (the value is kept for callers compiled against rounds 3 / 4, whose own
+                                 * F(2x2) kernel on 16x16x4 tiles, conv3x3_wino16, was retired in round 5)                  */
+#define W2XC_KERNEL_WINOGRAD32 4 /* mid layers: Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (conv3x3_wino), fp32 throughout;
+                                 * banding-invariant on minimum-halo row views; the last layer is its own launch             */
 #define W2XC_KERNEL_WINOGRAD4 5 /* mid layers with >= 64 output planes: Winograd F(4x4,3x3) (conv3x3_wino4) on planar activations, fp32
                                  * throughout: 2.25 multiplies per output instead of 4, interpolation points 0, +-3/4, +-3/2 (error against the
                                  * fp64 truth 1.6-1.9x the CPU oracle's own, 0.2-0.3 of the rtol 1e-4 gate on whole frames:
@@ -89,8 +91,8 @@ typedef struct w2xc_opts {
                                * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
                                * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
     int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path (the one-plane last layer inside the epilogue
-                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  Both Winograd
-                               * kernels carry the epilogue (conv3x3_wino4, the default, and conv3x3_wino16): W2XC_FUSION_AUTO = on,
+                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  The default
+                               * kernel conv3x3_wino4 carries the epilogue: W2XC_FUSION_AUTO = on,
                                * W2XC_FUSION_OFF runs conv3x3_last as its own launch.  Results stay inside the fp32 gate either way
                                * (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
                                * (The 16-bit modes: environment W2XC_SPLIT_FUSE_FIRST / _LAST.) */

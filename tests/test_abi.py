@@ -189,17 +189,18 @@ def test_argument_validation(w2xc, noise1_layers):
         ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
     assert e.value.code == w2xc.ERR_PLANES
     assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first"
-    # the one-plane last layer: inside conv3x3_wino4's / conv3x3_wino16's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
+    # the one-plane last layer: inside conv3x3_wino4's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
     fused = True   # W2XC_FUSION_AUTO = on
     assert ms.kernel_name(6) == ("conv3x3_last_gather" if fused else "conv3x3_last")
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_last"
-    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last_gather"
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_last_gather"
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last"   # (the F(2x2) kernel has no fused epilogue)
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_MFMA)) == "conv3x3_last"   # (no fused epilogue in that kernel)
-    assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino4 / conv3x3_wino16 leave 32 OUTPUT planes to conv3x3_wino)
+    assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino4 leaves 32 OUTPUT planes to conv3x3_wino)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_wino4"
-    assert ms.kernel_name(5, w2xc.make_opts(fusion=w2xc.FUSION_ON)) == MID_128   # (fusion does not change the mid-layer kernel: both Winograd kernels carry the epilogue)
+    assert ms.kernel_name(5, w2xc.make_opts(fusion=w2xc.FUSION_ON)) == MID_128   # (fusion does not change the mid-layer kernel)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma"          # per-call choice of the mid-layer kernel
-    assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_wino16"
+    assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_wino"      # (alias of _WINOGRAD32 since conv3x3_wino16 was retired)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD32)) == "conv3x3_wino"
     assert ms.kernel_name(0, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_first"     # (first / last layers have one fast kernel)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"

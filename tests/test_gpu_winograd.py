@@ -1,7 +1,7 @@
-"""The Winograd kernels of the fp32 mid layers -- conv3x3_wino16 (csrc/w2xc_wino16.hip, F(2x2,3x3) on v_mfma_f32_16x16x4_f32, W2XC_KERNEL_WINOGRAD)
-and conv3x3_wino (csrc/w2xc_wino.hip, v_mfma_f32_32x32x2_f32, round 2) -- against the direct fp32 MFMA kernel (conv3x3_mfma2) and the
+"""The Winograd kernels of the fp32 mid layers -- conv3x3_wino (csrc/w2xc_wino.hip, F(2x2,3x3) on v_mfma_f32_32x32x2_f32, W2XC_KERNEL_WINOGRAD32 and its
+alias W2XC_KERNEL_WINOGRAD) and conv3x3_wino4 (csrc/w2xc_wino4.hip, F(4x4,3x3), the default) -- against the direct fp32 MFMA kernel (conv3x3_mfma2) and the
 CPU oracle of Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159).  The kernel is chosen per call through
-w2xc_opts.kernel (W2XC_KERNEL_MFMA / _WINOGRAD / _WINOGRAD32), so all three run in this one process."""
+w2xc_opts.kernel, so all of them run in this one process.  (The round-3 F(2x2) kernel on 16x16x4 tiles, conv3x3_wino16, was retired in round 5.)"""
 import numpy as np
 import pytest
 
@@ -14,7 +14,7 @@ def gpu(w2xc):
     return w2xc
 
 
-KERNELS = {"conv3x3_wino16": "KERNEL_WINOGRAD", "conv3x3_wino": "KERNEL_WINOGRAD32", "conv3x3_mfma": "KERNEL_MFMA"}
+KERNELS = {"conv3x3_wino": "KERNEL_WINOGRAD32", "conv3x3_mfma": "KERNEL_MFMA"}
 
 
 def _opts(w, name, **kw):
@@ -47,7 +47,7 @@ def runs(gpu):
     return {name: _run(gpu, name) for name in KERNELS}
 
 
-@pytest.mark.parametrize("name", ["conv3x3_wino16", "conv3x3_wino"])
+@pytest.mark.parametrize("name", ["conv3x3_wino"])
 def test_winograd_vs_direct_mfma(gpu, runs, name):
     """same fp32 arithmetic type, other summation order: every output within 4e-6 of the output range of the direct MFMA kernel's
     (two fp32 summation orders differ by about that much: conv3x3_mfma2 vs the oracle is 3-4e-6 too); banding from odd and even rows
@@ -55,8 +55,8 @@ def test_winograd_vs_direct_mfma(gpu, runs, name):
     a, names_w = runs[name]
     b, names_d = runs["conv3x3_mfma"]
     assert name in names_w and name not in names_d
-    # every mid layer (32 / 64 / 128 planes in and out) takes a Winograd kernel (conv3x3_wino16 leaves 32 output planes to conv3x3_wino)
-    assert names_w.count("conv3x3_wino16") + names_w.count("conv3x3_wino") == names_d.count("conv3x3_mfma")
+    # every mid layer (32 / 64 / 128 planes in and out) takes the Winograd kernel
+    assert names_w.count("conv3x3_wino") == names_d.count("conv3x3_mfma")
     assert a.shape == b.shape and np.isfinite(a).all()
     err = np.abs(a - b).max() / np.abs(b).max()
     print("%s vs conv3x3_mfma2: max err %.2e of the output range" % (name, err))
@@ -70,11 +70,12 @@ def test_kernel_choice_per_call(gpu):
     assert ms.kernel_name(1) == ms.kernel_name(1, gpu.make_opts()) == "conv3x3_wino4"   # W2XC_KERNEL_AUTO
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_MFMA)) == "conv3x3_mfma"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD32)) == "conv3x3_wino"
+    assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD)) == "conv3x3_wino"       # (alias since conv3x3_wino16 was retired)
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_WINOGRAD4)) == "conv3x3_wino4"
     assert ms.kernel_name(1, gpu.make_opts(kernel=gpu.KERNEL_DIRECT)) == "conv3x3_direct"
 
 
-@pytest.mark.parametrize("name", ["conv3x3_wino16", "conv3x3_wino"])
+@pytest.mark.parametrize("name", ["conv3x3_wino"])
 @pytest.mark.parametrize("planes", [[1, 64, 64, 1], [1, 32, 128, 128, 1], [1, 64, 128, 64, 1], [1, 32, 32, 32, 1]])
 def test_winograd_vs_oracle(gpu, planes, name):
     """against the CPU oracle, rtol 1e-4 + atol 1e-5 (north_star) and max-norm 1e-5, on a plane that is not a multiple of the work item"""
@@ -82,20 +83,19 @@ def test_winograd_vs_oracle(gpu, planes, name):
     from tools import gen_model
     layers = gen_model.synth_layers(planes, 900 + len(planes))
     ms = gpu._ModelSet.from_layers(layers)
-    if planes != [1, 32, 32, 32, 1]:
-        assert name in [ms.kernel_name(l, _opts(gpu, name)) for l in range(len(planes) - 1)]
+    assert name in [ms.kernel_name(l, _opts(gpu, name)) for l in range(len(planes) - 1)]
     x = np.random.default_rng(11).random((75, 101), dtype=np.float32)
     got, want = ms.convert(x, opts=_opts(gpu, name)), orc.Oracle(layers).convert(x)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("mid", ["conv3x3_wino4", "conv3x3_wino16"])
+@pytest.mark.parametrize("mid", ["conv3x3_wino4"])
 @pytest.mark.parametrize("planes", [[1, 32, 32, 64, 64, 128, 128, 1], [1, 32, 64, 1], [1, 64, 128, 64, 1], [1, 32, 128, 1]])
 def test_fused_last_layer_fp32_vs_unfused(gpu, planes, mid):
     """N3 on the fp32 path: the one-plane last layer inside the epilogue of the DEFAULT kernel conv3x3_wino4 (taps-as-rows MFMAs on the activations the
-    epilogue has just produced, the four plane tiles of a 64-plane block summed on chip: Cout / 64 x 9 partial tap planes + conv3x3_last_gather) and of
-    conv3x3_wino16 (W2XC_KERNEL_WINOGRAD: Cout / 32 x 9 interleaved partials) against the separate conv3x3_last launch
+    epilogue has just produced, the four plane tiles of a 64-plane block summed on chip: Cout / 64 x 9 partial tap planes + conv3x3_last_gather)
+    against the separate conv3x3_last launch
     (w2xc_opts.fusion = W2XC_FUSION_ON / _OFF) and against the CPU oracle.  Same fp32 arithmetic type, the last layer's channel sum
     split in 32-plane partials: the two runs agree to the level two fp32 summation orders do.  Odd sizes, planes smaller than a
     work item, banding (bit-identical inside the fused run), the nearest-2x entry and the host pipeline's chunked path (>= 128 rows)."""
@@ -104,13 +104,13 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes, mid):
     layers = gen_model.synth_layers(planes, 77 + len(planes))
     ms = gpu._ModelSet.from_layers(layers)
     n = len(planes) - 1
-    kern = gpu.KERNEL_WINOGRAD4 if mid == "conv3x3_wino4" else gpu.KERNEL_WINOGRAD
+    kern = gpu.KERNEL_WINOGRAD4
     on, off = gpu.make_opts(fusion=gpu.FUSION_ON, kernel=kern), gpu.make_opts(fusion=gpu.FUSION_OFF, kernel=kern)
     assert ms.kernel_name(n - 1, on) == "conv3x3_last_gather" and ms.kernel_name(n - 2, on) == mid
     assert ms.kernel_name(n - 1, off) == "conv3x3_last"
     if mid == "conv3x3_wino4":   # ... and it is what the default options run
         assert ms.kernel_name(n - 1) == "conv3x3_last_gather" and ms.kernel_name(n - 2) == mid
-    gate = 4e-5 if mid == "conv3x3_wino4" else 1e-5   # (max-norm gates of the two kernels, test_wino4_f4x4_kernel / test_winograd16)
+    gate = 4e-5   # (the max-norm gate of the F(4x4) kernel on short models, test_wino4_f4x4_kernel)
     o = orc.Oracle(layers)
     worst = 0.0
     for (h, wd) in ((37, 61), (8, 32), (300, 170), (1, 1), (16, 33)):

@@ -99,47 +99,6 @@ def test_wino4_matrices_are_the_cook_toom_matrices_of_their_points(w2xc):
     assert np.abs(U - expect).max() <= 2.0 ** -23 * np.abs(expect).max()
 
 
-# ---- F(2x2,3x3): conv3x3_wino16 (w2xc_wino16.hip; W2XC_KERNEL_WINOGRAD, and the row-band fallback of W2XC_KERNEL_AUTO) ----
-BT2 = np.array([[1.0, 0.0, -1.0, 0.0], [0.0, 1.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.0], [0.0, 1.0, 0.0, -1.0]])
-AT2 = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
-
-
-def _pack16(w2xc, cin, cout, w):
-    lib = ctypes.CDLL(w2xc.LIB_PATH)
-    fn = getattr(lib, "_Z16w2xc_wino16_packiiPKfPf")
-    fn.restype = None
-    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    dst = np.zeros(16 * cin * cout, np.float32)
-    w = np.ascontiguousarray(w, np.float32)
-    fn(cin, cout, w.ctypes.data, dst.ctypes.data)
-    return dst
-
-
-def _unpack16(cin, cout, img):
-    """U[xi][plane][channel] from [ob][slice][st][pt][xi / 4][lane = 16 kq + o][xi % 4], channel = 8 slice + 2 kq + st (w2xc_wino16_pack's comment)."""
-    nsl, nob = cin // 8, cout // 32
-    a = img.reshape(nob, nsl, 2, 2, 4, 4, 16, 4)        # ob, sl, st, pt, xi >> 2, kq, o, xi & 3
-    a = a.transpose(4, 7, 0, 3, 6, 1, 5, 2)              # xi >> 2, xi & 3, ob, pt, o, sl, kq, st
-    return a.reshape(16, cout, cin)
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 64), (128, 128)])
-def test_wino16_weight_image_and_matrices_reproduce_the_3x3_correlation(w2xc, cin, cout):
-    rng = np.random.default_rng(cin * 1000 + cout + 1)
-    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
-    U = _unpack16(cin, cout, _pack16(w2xc, cin, cout, w)).astype(np.float64)
-    d = rng.standard_normal((cin, 4, 4)).astype(np.float32).astype(np.float64)
-    V = np.einsum("ia,cab,jb->cij", BT2, d, BT2).reshape(cin, 16)
-    M = np.einsum("xpc,cx->px", U, V).reshape(cout, 4, 4)
-    Y = np.einsum("ia,pab,jb->pij", AT2, M, AT2)
-    ref = np.zeros((cout, 2, 2))
-    for ky in range(3):
-        for kx in range(3):
-            ref += np.einsum("pc,cyx->pyx", w[:, :, ky, kx].astype(np.float64), d[:, ky:ky + 2, kx:kx + 2])
-    scale = np.abs(ref).max()
-    assert np.abs(Y - ref).max() <= 2e-6 * scale, (np.abs(Y - ref).max(), scale)
-
-
 # ---- the fp32 error of F(4x4,3x3) as the kernel orders it, emulated in numpy float32 ----
 def _bt6_f32(x0, x1, x2, x3, x4, x5):
     """bt6 of w2xc_wino4.hip on float32 arrays (numpy rounds the product and the sum separately where the kernel's fma rounds once: an upper bound)."""

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Per-layer hipEvent times of the 1080p -> 2160p frame (BASELINE configs[1]) for each fp32 mid-layer kernel, alternating in ONE
 process (boxes differ by 2-4 %): w2xc_opts.kernel = W2XC_KERNEL_MFMA / _WINOGRAD32 / _WINOGRAD.
-   python tools/frame_ab.py [--kernels wino16,wino32,mfma] [--rounds 3] [--steps 5] [--topo 1,32,32,64,64,128,128,1]"""
+   python tools/frame_ab.py [--kernels wino4,wino32,mfma] [--rounds 3] [--steps 5] [--topo 1,32,32,64,64,128,128,1]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as graft
 from tools import gen_model
 ap = argparse.ArgumentParser()
-ap.add_argument("--kernels", default="wino16,wino32")
+ap.add_argument("--kernels", default="wino4,wino32")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
@@ -16,7 +16,7 @@ ap.add_argument("--topo", default="1,32,32,64,64,128,128,1")
 ap.add_argument("--check", action="store_true", help="also print each kernel's max |difference| to the direct MFMA kernel over the output range")
 a = ap.parse_args()
 w2xc = graft.load_package()
-K = {"mfma": w2xc.KERNEL_MFMA, "wino32": w2xc.KERNEL_WINOGRAD32, "wino16": w2xc.KERNEL_WINOGRAD, "wino4": w2xc.KERNEL_WINOGRAD4, "auto": w2xc.KERNEL_AUTO}
+K = {"mfma": w2xc.KERNEL_MFMA, "wino32": w2xc.KERNEL_WINOGRAD32, "wino4": w2xc.KERNEL_WINOGRAD4, "auto": w2xc.KERNEL_AUTO}
 topo = [int(v) for v in a.topo.split(",")]
 ms = w2xc._ModelSet.from_layers(gen_model.synth_layers(topo, 102))
 x = torch.rand(a.h, a.w, device="cuda"); y = torch.empty_like(x)

@@ -41,10 +41,10 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         if k == NL and any("conv3x3_last_gather" in n for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
     if T == 0 and k == NL and any("conv3x3_last_gather" in n for n in stats):
-        sub = "conv3x3_last_gather"   # fp32: the last layer inside conv3x3_wino16's epilogue + this gather (w2xc_opts.fusion)
+        sub = "conv3x3_last_gather"   # fp32: the last layer inside conv3x3_wino4's epilogue + this gather (w2xc_opts.fusion)
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
-    if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino16<CIN, COUT, 0> / conv3x3_wino<CIN, COUT>)
-        for sub in ("conv3x3_wino4<%d, %d," % (cin, cout), "conv3x3_wino16<%d, %d," % (cin, cout), "conv3x3_wino<%d, %d" % (cin, cout)):
+    if not names and T == 0 and 1 < k < NL:            # Winograd kernel for this shape (conv3x3_wino4<CIN, COUT, ..> / conv3x3_wino<CIN, COUT>)
+        for sub in ("conv3x3_wino4<%d, %d," % (cin, cout), "conv3x3_wino<%d, %d" % (cin, cout)):
             names = [n for n in stats if sub in n]
             if names:
                 break
@@ -60,7 +60,7 @@ for k, (cin, cout) in enumerate(PLANES, 1):
     out_bpe = 4 if (T == 0 or k >= NL - 1) else 2 * T
     alg = (cin * in_bpe + cout * out_bpe) * px
     fused_fp32 = T == 0 and any("conv3x3_last_gather" in n for n in stats)
-    w4 = any("conv3x3_wino4<%d, %d," % PLANES[NL - 2] in n for n in stats)   # conv3x3_wino4 sums a 64-plane block's partials on chip, conv3x3_wino16 writes 32-plane partials
+    w4 = any("conv3x3_wino4<%d, %d," % PLANES[NL - 2] in n for n in stats)   # conv3x3_wino4 sums a 64-plane block's partials on chip
     if sub == "conv3x3_last_gather":
         alg = ((PLANES[NL - 2][1] // (64 if w4 else 32) if T == 0 else 2) * 9 * 4 + 4) * px   # partial tap planes in (Cout / 64 or / 32 blocks, or two halves), one plane out
     if fused_fp32 and k == NL - 1:

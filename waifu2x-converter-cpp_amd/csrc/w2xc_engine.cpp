@@ -81,13 +81,11 @@ struct DevLayer {
     float *w_fast = nullptr;
     float *w_direct = nullptr;
     float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path, 32x32x2 kernel), packed on first use
-    float *w_wino16 = nullptr;   // w2xc_wino16_pack image (fp32 Winograd path, 16x16x4 kernel), packed on first use
     float *w_wino4 = nullptr;    // w2xc_wino4_pack image (F(4x4,3x3) kernel), packed on first use
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
     float *w_last_fused[4] = {nullptr, nullptr, nullptr, nullptr};   // w2xc_split_pack_last images: [0] 2 bf16 terms, [1] 2 fp16 terms, [2] 3 bf16 terms, [3] 1 bf16 term
     float last_fused_scale[4] = {1, 1, 1, 1};
-    float *w_last_wino16 = nullptr;   // w2xc_wino16_pack_last image (fp32 path: last layer inside conv3x3_wino16's epilogue)
     float *w_last_wino4 = nullptr;    // w2xc_wino4_pack_last image (fp32 path: last layer inside conv3x3_wino4's epilogue)
     float *bias = nullptr;
 };
@@ -180,9 +178,7 @@ struct DevCtx {
             if (l.w_fast) hipFree(l.w_fast);
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_wino) hipFree(l.w_wino);
-            if (l.w_wino16) hipFree(l.w_wino16);
             if (l.w_wino4) hipFree(l.w_wino4);
-            if (l.w_last_wino16) hipFree(l.w_last_wino16);
             if (l.w_last_wino4) hipFree(l.w_last_wino4);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
@@ -326,7 +322,7 @@ bool fuse_last(const w2xc_model *m, const w2xc_opts &o)
 }
 
 // terms of layer l's OUTPUT in the split pipeline: T when layer l+1 is a split mid layer, else 0 (fp32); 9 = this layer writes
-// the partial tap planes of the last layer it computes in its epilogue (16-bit modes: conv3x3_split; fp32: conv3x3_wino16)
+// the partial tap planes of the last layer it computes in its epilogue (16-bit modes: conv3x3_split; fp32: conv3x3_wino4)
 int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     const int T = split_terms(o), n = (int)m->layers.size();
@@ -336,8 +332,8 @@ int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o)
     return layer_kind(m, l + 1, o) == W2XC_K_MID_SPLIT ? T : 0;
 }
 
-// partial-G planes a fused-last producer writes per tap: wave columns of the split tile shapes, 32-plane blocks of conv3x3_wino16
-int fused_halves(int T, int cout, bool wino4 = false) { return T > 0 ? w2xc_split_halves(T, cout) : wino4 ? cout / 64 : cout / 32; }
+// partial-G planes a fused-last producer writes per tap: wave columns of the split tile shapes, 64-plane blocks of conv3x3_wino4
+int fused_halves(int T, int cout) { return T > 0 ? w2xc_split_halves(T, cout) : cout / 64; }
 
 int upload(const std::vector<float> &h, float **d)
 {
@@ -415,33 +411,31 @@ int prof_begin(DevCtx *c, int layer, hipStream_t st, ProfEvent *ev)
 // fp32 path, layers with 32 / 64 / 128 planes in and out (W2XC_K_MFMA): which kernel runs them.
 //   MID_MFMA    conv3x3_mfma2: direct implicit GEMM, a k-ordered fp32 fma chain (the closest MFMA analogue of modelHandler.cpp:134-145)
 //   MID_WINO32  conv3x3_wino:   Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, one wave per SIMD (round 2)
-//   MID_WINO16  conv3x3_wino16: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two waves per SIMD (round 3; 64 / 128 output planes)
 // Same arithmetic type (fp32 throughout); Winograd does 2.25x fewer multiplies in another summation order and is held to the same
 // rtol 1e-4 gate against the CPU oracle by the same tests.  w2xc_opts.kernel picks per call (W2XC_KERNEL_MFMA / _WINOGRAD /
 // _WINOGRAD32 / _WINOGRAD4); W2XC_KERNEL_AUTO = W2XC_KERNEL_WINOGRAD4: conv3x3_wino4 (F(4x4,3x3)) where it applies (>= 64 output planes),
 // conv3x3_wino for the rest.  No environment variable takes part in the choice.
 //   MID_WINO4   conv3x3_wino4:  Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (round 3, the default: 1.78x fewer multiplies again, ~1.3x the rounding error of
 //               F(2x2); needs the four-rows-per-layer band geometry of run_rows to stay banding-invariant)
-enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO16 = 2, MID_WINO4 = 3 };
+enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO4 = 3 };
 int mid_variant(const w2xc_opts &o)
 {
     switch (o.kernel) {
     case W2XC_KERNEL_MFMA: return MID_MFMA;
-    case W2XC_KERNEL_WINOGRAD: return MID_WINO16;
+    case W2XC_KERNEL_WINOGRAD:     // (= _WINOGRAD32 since round 5: the round-3 F(2x2) kernel on 16x16x4 tiles, conv3x3_wino16, is retired)
     case W2XC_KERNEL_WINOGRAD32: return MID_WINO32;
     default: return MID_WINO4;   // W2XC_KERNEL_AUTO = W2XC_KERNEL_WINOGRAD4 (no environment switches: the choice is the caller's, per call)
     }
 }
-// the variant that really runs a (cin, cout) layer: conv3x3_wino16 needs two 32-plane groups (cout >= 64), the other Winograd kernel takes the rest
+// the variant that really runs a (cin, cout) layer: conv3x3_wino4 needs 64-plane output blocks, the F(2x2) kernel takes the rest
 int mid_variant_for(int midv, int cin, int cout)
 {
-    if (midv == MID_WINO4 && !w2xc_wino4_supported(cin, cout)) midv = MID_WINO16;
-    if (midv == MID_WINO16 && !w2xc_wino16_supported(cin, cout)) midv = MID_WINO32;
+    if (midv == MID_WINO4 && !w2xc_wino4_supported(cin, cout)) midv = MID_WINO32;
     if (midv == MID_WINO32 && !w2xc_wino_supported(cin, cout)) midv = MID_MFMA;
     return midv;
 }
 
-// the variant mid layer l really runs with these options (both conv3x3_wino4 and conv3x3_wino16 carry the fused last layer in their epilogue)
+// the variant mid layer l really runs with these options
 int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     const HostLayer &p = m->layers[l];
@@ -476,8 +470,8 @@ bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o)   // layout 
     return layer_kind(m, l + 1, o) == W2XC_K_DIRECT;   // (conv3x3_last reads NHWC at 5.4 TB/s; its planar variant measured half of that: NHWC out there)
 }
 
-// fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino16 (Cout 64 / 128):
-// the producer writes Cout / 32 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
+// fp32 path: the one-plane last layer inside the epilogue of the layer before it when that layer runs conv3x3_wino4 (Cout 64 / 128):
+// the producer writes Cout / 64 x 9 partial tap planes instead of Cout activation planes, conv3x3_last_gather finishes.
 // w2xc_opts.fusion = W2XC_FUSION_OFF / _ON decides per call; W2XC_FUSION_AUTO = on.
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
 {
@@ -487,7 +481,7 @@ bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
     const HostLayer &p = m->layers[n - 2], &q = m->layers[n - 1];
     if (q.nout != 1 || q.nin != p.nout || w2xc_pick_kernel(q.nin, 1) != W2XC_K_LAST || w2xc_pick_kernel(p.nin, p.nout) != W2XC_K_MFMA) return false;
     const int v = layer_mid_variant(m, n - 2, o);
-    return v == MID_WINO16 || v == MID_WINO4;
+    return v == MID_WINO4;
 }
 
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
@@ -532,11 +526,10 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
     const int midv = kind == W2XC_K_MFMA ? layer_mid_variant(m, l, o) : MID_MFMA;
     const bool wino = midv != MID_MFMA;
     if (wino) {
-        float *&img = midv == MID_WINO4 ? dl.w_wino4 : midv == MID_WINO16 ? dl.w_wino16 : dl.w_wino;
+        float *&img = midv == MID_WINO4 ? dl.w_wino4 : dl.w_wino;
         if (!img) {
             std::vector<float> pk(midv == MID_WINO4 ? (size_t)36 * d.cin * d.cout : w2xc_wino_packed_floats(d.cin, d.cout));
             if (midv == MID_WINO4) w2xc_wino4_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
-            else if (midv == MID_WINO16) w2xc_wino16_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
             else w2xc_wino_pack(d.cin, d.cout, m->layers[l].w.data(), pk.data());
             int rc = upload(pk, &img);
             if (rc) return rc;
@@ -544,23 +537,13 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         d.wpk = img;
         if (d.out_terms == 9) {   // the next (last) layer's weights ride along (fuse_last_fp32)
             DevLayer &nl = c->layers[l + 1];
-            if (midv == MID_WINO4) {
-                if (!nl.w_last_wino4) {
-                    std::vector<float> pk(w2xc_wino4_pack_last_floats(m->layers[l + 1].nin));
-                    w2xc_wino4_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
-                    int rc = upload(pk, &nl.w_last_wino4);
-                    if (rc) return rc;
-                }
-                d.w7pk = nl.w_last_wino4;
-            } else {
-                if (!nl.w_last_wino16) {
-                    std::vector<float> pk(w2xc_wino16_pack_last_floats(m->layers[l + 1].nin));
-                    w2xc_wino16_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
-                    int rc = upload(pk, &nl.w_last_wino16);
-                    if (rc) return rc;
-                }
-                d.w7pk = nl.w_last_wino16;
+            if (!nl.w_last_wino4) {
+                std::vector<float> pk(w2xc_wino4_pack_last_floats(m->layers[l + 1].nin));
+                w2xc_wino4_pack_last(m->layers[l + 1].nin, m->layers[l + 1].w.data(), pk.data());
+                int rc = upload(pk, &nl.w_last_wino4);
+                if (rc) return rc;
             }
+            d.w7pk = nl.w_last_wino4;
         }
     }
     d.bias = dl.bias;
@@ -571,7 +554,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                    : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
-                   : wino                        ? (midv == MID_WINO4 ? w2xc_launch_wino4(d, st) : midv == MID_WINO16 ? w2xc_launch_wino16(d, st) : w2xc_launch_wino(d, st))
+                   : wino                        ? (midv == MID_WINO4 ? w2xc_launch_wino4(d, st) : w2xc_launch_wino(d, st))
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
     if (profile) {
@@ -663,7 +646,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
             const size_t hk = (size_t)rows + ((HL == 1 || k == n) ? 2 * (n - k) : 6 + 8 * (n - k)), wk = (size_t)w + 2 * (n - k);
             const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
-            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout, is_wino4_layer(m, k - 1, o)) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
+            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
             const size_t wk_mem = planar_between(m, k - 1, o) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows start on 128-byte lines
             need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk_mem * px_bytes);
         }
@@ -785,23 +768,16 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     d.out_rs = d.out_w; d.out_ps = 1;
                     d.out_gs = (long long)d.out_h * d.out_w;
                     d.out_ts = 9 * d.out_gs;
-                    d.halves = fused_halves(T, hl.nout, is_wino4_layer(m, k - 1, o));
-                    if (T == 0 && !is_wino4_layer(m, k - 1, o)) {   // fp32, conv3x3_wino16: the partials interleaved, G[tap][y][x][half] -- the gather reads 16 bytes per tap and pixel
-                        // (conv3x3_wino4 writes planar partial planes G[64-plane block][tap][y][x]: its epilogue sums the four plane tiles of a block on chip)
-                        d.out_ps = d.halves; d.out_rs = (long long)d.out_w * d.halves;
-                        d.out_gs = (long long)d.out_h * d.out_w * d.halves;
-                        d.out_ts = 1;
-                    }
+                    d.halves = fused_halves(T, hl.nout);   // (fp32: conv3x3_wino4 writes planar partial planes G[64-plane block][tap][y][x]: its epilogue sums the four plane tiles of a block on chip)
                 }
             }
             // 16-bit modes, host pipeline: the last layer lives in layer n-1's epilogue + a 0.2 ms gather, too short to hide the
             // band's download behind.  So layer n-1 and the gather run TOGETHER in row chunks (quarters of the band, whole 16-row
             // tiles): chunk j's rows leave for the host under layer n-1 of chunk j+1.  The producer chunks tile the G rows without
             // overlap (chunk j computes G rows up to r1 + 2, the next one continues there): no recompute.
-            // (not conv3x3_wino4 as the producer -- an explicit W2XC_KERNEL_WINOGRAD4 on a narrow view: these chunks start at g_done = r1 + 2, not on a block
-            //  row, so its F(4x4) block grid would shift from chunk to chunk; the tail path below cuts it on whole 16-row tiles)
-            if (hk && HL == 1 && k == n - 1 && n >= 3 && (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_MFMA) && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
-                !is_wino4_layer(m, k - 1, o) && hk->output_ready && (y1 - y0) >= 128) {   // (HL = 4: the producer's rows do not start one above the band's: the unchunked path)
+            // (16-bit producers only: conv3x3_wino4's fused epilogue wants chunks on whole 16-row tiles of ITS block grid -- the tail path below)
+            if (hk && HL == 1 && k == n - 1 && n >= 3 && kind == W2XC_K_MID_SPLIT && d.out_terms == 9 && last_direct && hk->out_chunk_rows > 0 &&
+                hk->output_ready && (y1 - y0) >= 128) {
                 if (hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
                 const int R = y1 - y0;
                 const int cr = std::max(64, ((R / 4) + 15) & ~15);
@@ -2308,7 +2284,7 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     const W2xcKernelKind k = layer_kind(m, layer, o);
     if (k == W2XC_K_MFMA) {
         const int midv = layer_mid_variant(m, layer, o);
-        if (midv != MID_MFMA) return midv == MID_WINO4 ? "conv3x3_wino4" : midv == MID_WINO16 ? "conv3x3_wino16" : "conv3x3_wino";
+        if (midv != MID_MFMA) return midv == MID_WINO4 ? "conv3x3_wino4" : "conv3x3_wino";
     }
     return w2xc_kernel_name(k, m->layers[layer].nin, m->layers[layer].nout);
 }

@@ -78,9 +78,6 @@ bool w2xc_wino_supported(int cin, int cout);
 size_t w2xc_wino_packed_floats(int cin, int cout);
 void w2xc_wino_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
-// the same layer on v_mfma_f32_16x16x4_f32 with 128 accumulators per wave and two workgroups per CU (w2xc_wino16.hip);
-// d.wpk = the w2xc_wino16_pack image (16 * cin * cout floats, another fragment order)
-bool w2xc_wino16_supported(int cin, int cout);
 // Winograd F(4x4,3x3) on PLANAR activations (w2xc_wino4.hip): in_ps = 1 / in_cs = plane stride; out planar (out_ps = 1) or NHWC (out_cs = 1, out_ps = cout);
 // d.wpk = the w2xc_wino4_pack image (36 * cin * cout floats), d.wino_py = first output row mod 4, off_x a non-negative multiple of 4
 bool w2xc_wino4_supported(int cin, int cout);
@@ -90,12 +87,6 @@ hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
 // G[64-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 64
 size_t w2xc_wino4_pack_last_floats(int cin);
 void w2xc_wino4_pack_last(int cin, const float *w, float *dst);
-void w2xc_wino16_pack(int cin, int cout, const float *w, float *dst);
-hipError_t w2xc_launch_wino16(const W2xcConvDesc &d, hipStream_t stream);
-// d.out_terms = 9: the one-plane LAST layer is computed in this layer's epilogue; d.w7pk = w2xc_wino16_pack_last image of its weights,
-// `out` = partial tap planes G[32-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 32
-size_t w2xc_wino16_pack_last_floats(int cin);
-void w2xc_wino16_pack_last(int cin, const float *w, float *dst);
 
 // split kernels (w2xc_split.hip).  Packed weights of a mid layer: `terms` 16-bit terms of every weight in
 // fragment order; W2XC_K_FIRST_SPLIT uses the W2XC_K_FIRST image.

@@ -1025,39 +1025,11 @@ __global__ void __launch_bounds__(256) conv3x3_last_gather_x4(const float *G, in
     }
 }
 
-// The same sum for partial planes stored INTERLEAVED, G[tap][y][x][H] (the fp32 fused last layer of conv3x3_wino16 writes that: half stride 1,
-// pixel stride H): one 8- / 16-byte load per tap and pixel instead of H dwords from H planes, fully coalesced.
-template <int H>
-__global__ void __launch_bounds__(256) conv3x3_last_gather_il(const float *G, long long ps, long long rs, const float *bias, float *out, long long out_rs,
-                                                              long long out_ps, int out_h, int out_w)
-{
-    typedef float vecH __attribute__((ext_vector_type(H)));
-    const long long total = (long long)out_h * out_w;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int y = (int)(idx / out_w), x = (int)(idx - (long long)y * out_w);
-        vecH acc = {};
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++)
-            acc += *reinterpret_cast<const vecH *>(G + tap * ps + (long long)(y + tap / 3) * rs + (long long)(x + tap % 3) * H);
-        float v = 0.0f;
-#pragma unroll
-        for (int h = 0; h < H; h++) v += acc[h];
-        out[(long long)y * out_rs + (long long)x * out_ps] = leaky(v + bias[0]);
-    }
-}
-
 hipError_t w2xc_launch_last_gather(const W2xcConvDesc &d, hipStream_t stream)
 {
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     const long long total = (long long)d.out_h * d.out_w;
     int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    if (d.in_ts == 1 && d.in_ps == d.halves && (d.halves == 2 || d.halves == 4) && ((size_t)d.in % (4 * d.halves)) == 0 && (d.in_rs % d.halves) == 0 && (d.in_gs % d.halves) == 0) {
-        if (d.halves == 4)
-            hipLaunchKernelGGL(conv3x3_last_gather_il<4>, dim3(grid), dim3(256), 0, stream, d.in, d.in_gs, d.in_rs, d.bias, d.out, d.out_rs, d.out_ps, d.out_h, d.out_w);
-        else
-            hipLaunchKernelGGL(conv3x3_last_gather_il<2>, dim3(grid), dim3(256), 0, stream, d.in, d.in_gs, d.in_rs, d.bias, d.out, d.out_rs, d.out_ps, d.out_h, d.out_w);
-        return hipGetLastError();
-    }
     if (d.in_ps <= 1 && d.out_ps == 1) {   // planar partial planes, contiguous output pixels: four pixels per thread (0.19 -> 0.11 ms per 2160x3840 frame)
         const long long groups = (long long)d.out_h * ((d.out_w + 3) >> 2);
         grid = (int)((groups + 255) / 256 < 65536 ? (groups + 255) / 256 : 65536);

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino(W2xcConvDesc d, int tiles
     constexpr unsigned B_BYTES = 32 * 1024;                // U of one (plane block, slice)
     constexpr unsigned B_BASE = 2 * A_BYTES;
     static_assert(CIN % 16 == 0 && COUT % 32 == 0, "planes");
-    // pixel tiles are walked in strips of 32 tiles, row by row inside a strip (conv3x3_wino16 explains: the next round of an XCD is the tile
+    // pixel tiles are walked in strips of 32 tiles, row by row inside a strip (the next round of an XCD is the tile
     // row below, whose halo rows are still in that XCD's L2)
     constexpr int STRIP = 32;
     const int tiles_y = nitems / (NOB * tiles_x);
