@@ -540,7 +540,7 @@ def main():
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
         def issued(l):   # fraction of a layer's algorithmic multiplies its kernel issues (Winograd F(2x2,3x3): 16 of 36; F(4x4,3x3): 36 of 144)
             name = ms.kernel_name(l, opts)
-            return 0.25 if name == "conv3x3_wino4" else 16.0 / 36.0 if "wino" in name else 1.0
+            return 0.25 if "wino4" in name else 16.0 / 36.0 if "wino" in name else 1.0   # (conv3x3_wino4, conv3x3_first2_wino4: F(4x4); conv3x3_wino: F(2x2))
         algorithmic = products * dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # a fused last layer's MFMAs are issued by the dominant kernel too (taps-as-rows on 16x16x4 tiles: 16 rows x cin per pixel, 9 of them useful)
         fused_last = dom + 1 == n_layers - 1 and ms.kernel_name(dom + 1, opts) == "conv3x3_last_gather" and args.precision == "fp32"
@@ -563,6 +563,8 @@ def main():
                               # SURVEY 8(d)'s algorithmic FLOPs over the same time
                               "algorithmic_tflops": round(alg_tf, 2) if ms_l > 0 else None,
                               "algorithmic_GBs_fp32_nhwc": round(alg_bytes / (ms_l * 1e-3) / 1e9, 1) if ms_l > 0 else None})
+            if per_layer[-1]["kernel"] == "(in_next_layer)":
+                per_layer[-1]["note"] = "layer 1 has no launch of its own: it is computed inside the next layer's kernel (conv3x3_first2_wino4), whose `ms` includes it"
             if per_layer[-1]["kernel"] == "conv3x3_last_gather":
                 for kf in ("tflops", "frac_of_peak", "algorithmic_tflops", "algorithmic_GBs_fp32_nhwc"):
                     per_layer[-1][kf] = None   # (this launch adds 9 x Cout/64 partial values per pixel: the layer's multiplies are in the previous launch)

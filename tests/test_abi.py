@@ -188,7 +188,11 @@ def test_argument_validation(w2xc, noise1_layers):
     with pytest.raises(w2xc.W2xcError) as e:
         ms.filter(1, np.zeros((5, 4, 4), np.float32))     # 5 planes into a 32-plane layer (:29-35)
     assert e.value.code == w2xc.ERR_PLANES
-    assert ms.kernel_name(5) == MID_128 and ms.kernel_name(0) == "conv3x3_first"
+    assert ms.kernel_name(5) == MID_128
+    # layers 1 + 2 (1 -> 32 -> 32) in one launch under the default kernels (N3): layer 1 has no launch of its own unless fusion is off
+    assert ms.kernel_name(0) == "(in_next_layer)" and ms.kernel_name(1) == "conv3x3_first2_wino4"
+    assert ms.kernel_name(0, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_first" and ms.kernel_name(1, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_wino"
+    assert ms.kernel_name(1, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma" and ms.kernel_name(1, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
     # the one-plane last layer: inside conv3x3_wino4's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
     fused = True   # W2XC_FUSION_AUTO = on
     assert ms.kernel_name(6) == ("conv3x3_last_gather" if fused else "conv3x3_last")
@@ -196,7 +200,6 @@ def test_argument_validation(w2xc, noise1_layers):
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_last_gather"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last"   # (the F(2x2) kernel has no fused epilogue)
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_MFMA)) == "conv3x3_last"   # (no fused epilogue in that kernel)
-    assert ms.kernel_name(1) in (MID_128, "conv3x3_wino")  # 32 -> 32 too (conv3x3_wino4 leaves 32 OUTPUT planes to conv3x3_wino)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_wino4"
     assert ms.kernel_name(5, w2xc.make_opts(fusion=w2xc.FUSION_ON)) == MID_128   # (fusion does not change the mid-layer kernel)
     assert ms.kernel_name(5, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma"          # per-call choice of the mid-layer kernel

@@ -196,7 +196,12 @@ def test_device_pointer_entry_point(gpu, scale_layers):
     side.synchronize()
     assert_close(d_out.cpu().numpy(), want, "device entry")
     ms_t, launches = ms.profile_read(0)
-    assert launches == [1] * 7 and all(t > 0 for t in ms_t)
+    # (layers 1 + 2 are one launch under the default kernels: layer 1 has none of its own)
+    assert launches == [0] + [1] * 6 and ms_t[0] == 0 and all(t > 0 for t in ms_t[1:]) and ms.kernel_name(1) == "conv3x3_first2_wino4"
+    ms.profile_reset(0)
+    ms.convert_device(d_in.data_ptr(), 200 * 4, 200, 120, d_out.data_ptr(), 200 * 4, stream=side.cuda_stream, opts=gpu.make_opts(device=0, profile=1, fusion=gpu.FUSION_OFF))
+    side.synchronize()
+    assert ms.profile_read(0)[1] == [1] * 7
 
 
 @pytest.mark.parametrize("precision", [0, 3, 4])   # fp32, BF16X3, FP16X2

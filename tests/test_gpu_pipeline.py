@@ -340,7 +340,7 @@ def test_bench_line_single_gpu(gpu):
     assert abs((r["flops_per_launch"] - r["fused_last_layer_flops_per_launch"]) / r["algorithmic_flops_per_launch"] -
                (36 / 144 if "conv3x3_wino4" in r["kernel"] else 16 / 36 if "wino" in r["kernel"] else 1.0)) < 1e-9   # F(4x4,3x3) / F(2x2,3x3) / direct
     assert r["fused_last_layer_flops_per_launch"] == (0 if j["layers"][6]["kernel"] == "conv3x3_last" else r["fused_last_layer_flops_per_launch"]) >= 0
-    assert all(0 < l["frac_of_peak"] < 1 for l in j["layers"] if l["frac_of_peak"] is not None) and sum(l["frac_of_peak"] is None for l in j["layers"]) <= 1
+    assert all(0 < l["frac_of_peak"] < 1 for l in j["layers"] if l["frac_of_peak"] is not None) and sum(l["frac_of_peak"] is None for l in j["layers"]) <= 2   # (layer 1 inside layer 2's launch, the last layer inside layer 6's)
     assert ("conv3x3_wino" in r["kernel"] or "conv3x3_mfma" in r["kernel"]) and "128->128" in r["kernel"]
     assert len(j["layers"]) == 7 and "workload" in j["config"]
     assert abs(r["frac"] - j["layers"][5]["frac_of_peak"]) < 2e-4   # one accounting for the dominant launch in both places

@@ -127,6 +127,57 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes, mid):
     assert worst <= 4e-6, worst
 
 
+@pytest.mark.parametrize("planes", [[1, 32, 32, 64, 64, 128, 128, 1], [1, 32, 32, 64, 32, 1], [1, 32, 32, 128, 64, 1]])
+def test_fused_first_layers_fp32_vs_unfused(gpu, planes):
+    """N3 on the fp32 path, the front end: layers 1 (1 -> 32) and 2 (32 -> 32) in ONE launch (conv3x3_first2_wino4: layer 1 on the fly per Winograd patch,
+    layer 2 as F(4x4,3x3) with register-stationary weights; convertRoutine.cpp:66-76's loop collapsed by one more iteration) against the separate launches
+    conv3x3_first + conv3x3_wino (w2xc_opts.fusion = W2XC_FUSION_OFF), against the CPU oracle, across bandings (bit-identical), through the nearest-2x entry
+    (the upscale folded into the fused kernel's tile fill), through the host pipeline (chunked under the upload: bit-identical to resident) and as
+    row shards (bit-identical).  The two forms differ like two fp32 summation orders do (layer 2 runs F(4x4) fused, F(2x2) alone)."""
+    from oracle import oracle as orc
+    from tools import gen_model
+    torch = pytest.importorskip("torch")
+    layers = gen_model.synth_layers(planes, 500 + len(planes))
+    ms = gpu._ModelSet.from_layers(layers)
+    on, off = gpu.make_opts(), gpu.make_opts(fusion=gpu.FUSION_OFF)
+    assert ms.kernel_name(0, on) == "(in_next_layer)" and ms.kernel_name(1, on) == "conv3x3_first2_wino4"
+    assert ms.kernel_name(0, off) == "conv3x3_first" and ms.kernel_name(1, off) == "conv3x3_wino"
+    o = orc.Oracle(layers)
+    worst = 0.0
+    for (h, wd) in ((37, 61), (8, 32), (300, 170), (1, 1), (16, 33), (129, 257)):
+        x = np.random.default_rng(h * 13 + wd).random((h, wd), dtype=np.float32)
+        a, b = ms.convert(x, opts=on), ms.convert(x, opts=off)
+        worst = max(worst, float(np.abs(a - b).max() / np.abs(b).max()))
+        for band in (1, 7, 64):
+            assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(band_rows=band))), ("banding", planes, h, wd, band)
+        want = o.convert(x, njob=8)
+        assert np.allclose(a, want, rtol=1e-4, atol=1e-5) and np.abs(a - want).max() <= 4e-5 * np.abs(want).max()
+        a2, b2 = ms.convert_nn2x(x, opts=on), ms.convert_nn2x(x, opts=off)
+        worst = max(worst, float(np.abs(a2 - b2).max() / np.abs(b2).max()))
+        assert np.array_equal(a2, ms.convert(np.repeat(np.repeat(x, 2, 0), 2, 1), opts=on))   # the folded nearest-2x == the explicit one
+        # resident (device pointers) == host pipeline, bit for bit
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        ms.convert_device(d_in.data_ptr(), wd * 4, wd, h, d_out.data_ptr(), wd * 4, opts=gpu.make_opts(device=0))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), a)
+    # row shards with the wide halo stitch to the whole plane
+    h, wd = 150, 90
+    x = np.random.default_rng(3).random((h, wd), dtype=np.float32)
+    whole = ms.convert(x)
+    n = len(planes) - 1
+    out = torch.zeros((h, wd), dtype=torch.float32, device="cuda")
+    for p in range(3):
+        ra, rb = gpu.shard_rows(h, 3, p)
+        y0, y1 = gpu.shard_view(h, ra, rb, 4 * n)
+        view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
+        ms.convert_rows_device(view.data_ptr(), wd * 4, y1 - y0, y0, wd, h, ra, rb, out[ra:].data_ptr(), wd * 4, opts=gpu.make_opts(device=0))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole)
+    print("fused vs unfused first two layers, %s: max err %.2e of the output range" % (planes, worst))
+    assert worst <= 6e-6, worst
+
+
 def test_wino4_f4x4_kernel(gpu):
     """conv3x3_wino4 (csrc/w2xc_wino4.hip): Winograd F(4x4,3x3) on the fp32 MFMA, the default mid-layer kernel since round 3 (layers with >= 64 output
     planes; the others take the F(2x2) kernels), here asked for through w2xc_opts.kernel = W2XC_KERNEL_WINOGRAD4.  Same fp32 arithmetic type and the same

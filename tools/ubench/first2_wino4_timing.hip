@@ -1,7 +1,7 @@
 // conv3x3_first2_wino4 alone (layers 1 + 2 fused: 1 -> 32 -> 32): correctness against a double-precision direct evaluation of both layers on sampled outputs, time per launch.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize [-DW4S_ABL=n] [-DW4S_TIMING] -I../../waifu2x-converter-cpp_amd/csrc first2_wino4_timing.hip -o first2_wino4_timing
 //   ./first2_wino4_timing [h w [wino_py [off [in_shift]]]]     off: layer 1's offset (<= 0: replicate padding folded into the loads), h x w = layer 2's output
-#include "first2_wino4.hip"
+#include "w2xc_first2_wino4.hip"
 #include <cmath>
 #include <cstdio>
 #include <vector>

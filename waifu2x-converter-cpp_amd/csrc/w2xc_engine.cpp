@@ -81,6 +81,7 @@ struct DevLayer {
     float *w_fast = nullptr;
     float *w_direct = nullptr;
     float *w_wino = nullptr;     // w2xc_wino_pack image (fp32 Winograd path, 32x32x2 kernel), packed on first use
+    float *w_first2 = nullptr;  // w2xc_first2_wino4_pack image (layer 2 of the fused first two layers), packed on first use
     float *w_wino4 = nullptr;    // w2xc_wino4_pack image (F(4x4,3x3) kernel), packed on first use
     float *w_split[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // conv3x3_split images, index terms + 3*fmt, packed on first use
     float split_scale[6] = {1, 1, 1, 1, 1, 1};                                   // power-of-two weight scale of each image
@@ -179,6 +180,7 @@ struct DevCtx {
             if (l.w_direct) hipFree(l.w_direct);
             if (l.w_wino) hipFree(l.w_wino);
             if (l.w_wino4) hipFree(l.w_wino4);
+            if (l.w_first2) hipFree(l.w_first2);
             if (l.w_last_wino4) hipFree(l.w_last_wino4);
             for (float *p : l.w_split)
                 if (p) hipFree(p);
@@ -271,6 +273,7 @@ int split_fmt(const w2xc_opts &o) { return o.precision == W2XC_PRECISION_FP16X2 
 
 bool fuse_last(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o);
+bool fuse_first_fp32(const w2xc_model *m, const w2xc_opts &o);
 bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o);
 bool is_wino4_layer(const w2xc_model *m, int l, const w2xc_opts &o);
 int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o);
@@ -293,6 +296,7 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
         return W2XC_K_DIRECT;   // run_rows rejects this
     }
     if (k == W2XC_K_LAST && l == n - 1 && fuse_last_fp32(m, o)) return W2XC_K_LAST_GATHER;
+    if (l <= 1 && fuse_first_fp32(m, o)) return l == 0 ? W2XC_K_FUSED_AWAY : W2XC_K_FIRST2_WINO4;
     return k;
 }
 
@@ -465,6 +469,7 @@ bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o)   // layout 
 {
     const int n = (int)m->layers.size();
     if (l < 0 || l + 1 >= n) return false;
+    if (l == 1 && fuse_first_fp32(m, o)) return true;   // (conv3x3_first2_wino4 writes planar planes; conv3x3_wino4<32, .> reads either)
     if (is_wino4_layer(m, l + 1, o)) return m->layers[l + 1].nin != 32;   // (32 input planes: conv3x3_wino4 reads the producer's NHWC pixels, one 128-byte line each)
     if (!is_wino4_layer(m, l, o)) return false;
     return layer_kind(m, l + 1, o) == W2XC_K_DIRECT;   // (conv3x3_last reads NHWC at 5.4 TB/s; its planar variant measured half of that: NHWC out there)
@@ -484,12 +489,26 @@ bool fuse_last_fp32(const w2xc_model *m, const w2xc_opts &o)
     return v == MID_WINO4;
 }
 
+// fp32 path: layers 1 (ONE plane -> 32) and 2 (32 -> 32) in one launch (conv3x3_first2_wino4: layer 1 on the fly per Winograd patch, layer 2 as F(4x4,3x3)
+// with its weights stationary in registers) when the default kernels run the model and layer 3 reads planar planes (a conv3x3_wino4 layer).  Layer 1's 32
+// activation planes never reach HBM (convertRoutine.cpp:66-76's loop collapsed by one more launch).  w2xc_opts.fusion = W2XC_FUSION_OFF disables.
+bool fuse_first_fp32(const w2xc_model *m, const w2xc_opts &o)
+{
+    const int n = (int)m->layers.size();
+    if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || n < 3 || o.fusion == W2XC_FUSION_OFF) return false;
+    if (o.kernel != W2XC_KERNEL_AUTO && o.kernel != W2XC_KERNEL_WINOGRAD4) return false;
+    const HostLayer &a = m->layers[0], &b = m->layers[1];
+    if (!w2xc_first2_wino4_supported(a.nin, a.nout, b.nout) || b.nin != a.nout) return false;
+    if (n == 4 && fuse_last_fp32(m, o)) return false;   // (layer 3 would carry the fused last layer: that instantiation reads 32 NHWC planes only)
+    return is_wino4_layer(m, 2, o);   // (layer 3 = conv3x3_wino4: it reads layer 2's planar planes)
+}
+
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o)
 {
     DevLayer &dl = c->layers[l];
     d.cin = m->layers[l].nin;
     d.cout = m->layers[l].nout;
-    if (kind == W2XC_K_FUSED_AWAY) return W2XC_OK;   // computed by the next layer's W2XC_K_FIRST2_SPLIT launch
+    if (kind == W2XC_K_FUSED_AWAY) return W2XC_OK;   // computed by the next layer's W2XC_K_FIRST2_SPLIT / W2XC_K_FIRST2_WINO4 launch
     if (kind == W2XC_K_MID_SPLIT || kind == W2XC_K_FIRST2_SPLIT) {
         if (d.terms < 1 || d.terms > 3 || d.fmt < 0 || d.fmt > 1) return fail(W2XC_ERR_ARG, "bad term count %d / format %d", d.terms, d.fmt);
         const int wi = d.terms + 3 * d.fmt;
@@ -520,6 +539,16 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
         }
     } else if (kind == W2XC_K_LAST_GATHER) {
         d.wpk = nullptr;
+    } else if (kind == W2XC_K_FIRST2_WINO4) {
+        if (!dl.w_first2) {
+            std::vector<float> pk((size_t)36 * d.cin * d.cout);
+            w2xc_first2_wino4_pack(m->layers[l].w.data(), pk.data());
+            int rc = upload(pk, &dl.w_first2);
+            if (rc) return rc;
+        }
+        d.wpk = dl.w_first2;
+        d.w1pk = c->layers[l - 1].w_fast;
+        d.bias1 = c->layers[l - 1].bias;
     } else {
         d.wpk = kind == W2XC_K_DIRECT ? dl.w_direct : dl.w_fast;
     }
@@ -554,6 +583,7 @@ int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2x
                    : kind == W2XC_K_FIRST_SPLIT ? w2xc_launch_split_first(d, st)
                    : kind == W2XC_K_LAST_GATHER ? w2xc_launch_last_gather(d, st)
                    : kind == W2XC_K_FIRST2_SPLIT ? w2xc_launch_first2_split(d, st)
+                   : kind == W2XC_K_FIRST2_WINO4 ? w2xc_launch_first2_wino4(d, st)
                    : wino                        ? (midv == MID_WINO4 ? w2xc_launch_wino4(d, st) : w2xc_launch_wino(d, st))
                                                 : w2xc_launch_conv(kind, d, st);
     if (e != hipSuccess) return fail(W2XC_ERR_HIP, "launch of %s (layer %d, %d->%d) failed: %s", w2xc_kernel_name(kind, d.cin, d.cout), l, d.cin, d.cout, hipGetErrorString(e));
@@ -693,7 +723,8 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         const int y1 = std::min(rb, y0 + band);
         // layer 1 of this band in row chunks (each waits only for the rows it reads) or in one launch behind the whole upload
         const W2xcKernelKind kind1 = layer_kind(m, 0, o);
-        const int in_chunk = (hk && hk->in_chunk && hk->input_upto && n > 1 && (kind1 == W2XC_K_FIRST || kind1 == W2XC_K_DIRECT)) ? hk->in_chunk(y0, y1) : 0;
+        const bool first2_fp32 = kind1 == W2XC_K_FUSED_AWAY && n > 1 && layer_kind(m, 1, o) == W2XC_K_FIRST2_WINO4;   // (layers 1 + 2 in one launch: chunked like layer 1)
+        const int in_chunk = (hk && hk->in_chunk && hk->input_upto && n > 1 && (kind1 == W2XC_K_FIRST || kind1 == W2XC_K_DIRECT || first2_fp32)) ? hk->in_chunk(y0, y1) : 0;
         if (hk && hk->input_needed && in_chunk <= 0) { int rc = hk->input_needed(y0, y1); if (rc) return rc; }
         const float *src = d_in;
         long long src_rs = (long long)in_stride_f, src_ps = 1, src_cs = in_cs, src_ts = 0, src_gs = 0;
@@ -717,9 +748,9 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             Tprev = Tk;
             d.off_x = k == 1 ? -n : 0;
             // this launch's first output row in the coordinates of the whole plane, modulo the Winograd block height (2; conv3x3_wino4: 4)
-            d.wino_py = Tk & ((w2xc_pick_kernel(hl.nin, hl.nout) == W2XC_K_MFMA && layer_mid_variant(m, k - 1, o) == MID_WINO4) ? 3 : 1);
-            d.in_shift = k == 1 ? up : 0;
             const W2xcKernelKind kind = layer_kind(m, k - 1, o);
+            d.wino_py = Tk & (((w2xc_pick_kernel(hl.nin, hl.nout) == W2XC_K_MFMA && layer_mid_variant(m, k - 1, o) == MID_WINO4) || kind == W2XC_K_FIRST2_WINO4) ? 3 : 1);
+            d.in_shift = k == 1 ? up : 0;
             if (kind == W2XC_K_FUSED_AWAY) {   // layer 1 inside layer 2's kernel: keep its input description for that launch
                 first_d = d;
                 continue;
@@ -728,6 +759,11 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 d.in = first_d.in; d.in_rs = first_d.in_rs; d.in_ps = first_d.in_ps; d.in_cs = first_d.in_cs;
                 d.in_h = first_d.in_h; d.in_w = first_d.in_w;
                 d.off_y = first_d.off_y; d.off_x = first_d.off_x; d.in_shift = first_d.in_shift;
+            }
+            if (kind == W2XC_K_FIRST2_WINO4) {   // layer 1's input view; a source row of layer 2's output row y, taps r' and r: y + r' + r + (both offsets)
+                d.in = first_d.in; d.in_rs = first_d.in_rs; d.in_ps = first_d.in_ps; d.in_cs = first_d.in_cs;
+                d.in_h = first_d.in_h; d.in_w = first_d.in_w;
+                d.off_y += first_d.off_y; d.off_x += first_d.off_x; d.in_shift = first_d.in_shift;
             }
             int split_grp = 0;
             if (T == 0) {   // fp32: only the fused last layer uses the term fields
@@ -877,18 +913,20 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 int rc = hk->prefetch(y1, std::min(rb, y1 + band));
                 if (rc) return rc;
             }
-            if (k == 1 && in_chunk > 0) {
+            if ((k == 1 || kind == W2XC_K_FIRST2_WINO4) && in_chunk > 0) {
                 // the upload of rows [c0 + 2 + off_y ...] and layer 1 of the rows before them overlap: what stays exposed of the
-                // input side is the first slice and the last chunk, not upload + layer 1 back to back
+                // input side is the first slice and the last chunk, not upload + layer 1 back to back.  (Layers 1 + 2 in one launch: the same,
+                // two rows deeper; chunks of whole 8-row tiles keep the 4x4 blocks where the unchunked launch has them.)
+                const int reach = kind == W2XC_K_FIRST2_WINO4 ? 4 : 2;
                 for (int c0 = 0; c0 < d.out_h; c0 += in_chunk) {
                     W2xcConvDesc dd = d;
                     dd.out_h = std::min(in_chunk, d.out_h - c0);
                     dd.out = d.out + (size_t)c0 * d.out_rs;
                     dd.off_y = d.off_y + c0;
-                    const int vlast = std::min(std::max(c0 + dd.out_h - 1 + 2 + d.off_y, 0), d.in_h - 1);   // last view row this chunk reads
+                    const int vlast = std::min(std::max(c0 + dd.out_h - 1 + reach + d.off_y, 0), d.in_h - 1);   // last view row this chunk reads
                     int rc = hk->input_upto(vlast);
                     if (rc) return rc;
-                    rc = launch_layer(c, m, 0, kind, dd, st, o);
+                    rc = launch_layer(c, m, k - 1, kind, dd, st, o);
                     if (rc) return rc;
                 }
                 src = d.out; src_rs = d.out_rs; src_ps = d.out_ps; src_cs = d.out_cs; src_ts = d.out_ts; src_gs = d.out_gs; src_halves = d.halves;

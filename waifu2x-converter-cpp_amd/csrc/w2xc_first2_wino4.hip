@@ -1,4 +1,4 @@
-// w2xc_wino4s.hip -- conv3x3_first2_wino4: layers 1 (ONE plane -> 32) and 2 (32 -> 32) of convertWithModelsBasic's loop
+// w2xc_first2_wino4.hip -- conv3x3_first2_wino4: layers 1 (ONE plane -> 32) and 2 (32 -> 32) of convertWithModelsBasic's loop
 // (/root/reference/src/convertRoutine.cpp:66-76) in ONE launch: layer 1's activations never reach HBM (N3).  Layer 2 -- the 3x3 x 32 x 32
 // contraction of Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159) -- runs as Winograd F(4x4, 3x3) on v_mfma_f32_16x16x4_f32 with its
 // weights STATIONARY IN REGISTERS; layer 1 (9 multiplies per value) is computed on the fly, per Winograd patch, from a tile of the source plane.
@@ -41,7 +41,7 @@
 #define W4S_ABL 0   // timing-only ablations (wrong results): 1 no input transform arithmetic | 2 no layer-1 arithmetic | 4 no MFMAs | 8 no output transform | 16 no stores
 #endif
 #ifdef W4S_TIMING
-// tools/ubench/wino4s_timing.hip: s_memtime stamps of workgroup 0, wave 0: [tile * 8 + k], k = 0 tile start, 1 source tile in LDS, 2 T done, 3 barrier, 4 G done, 5 barrier + X done, 6 barrier, 7 O done
+// tools/ubench/first2_wino4_timing.hip: s_memtime stamps of workgroup 0, wave 0: [tile * 8 + k], k = 0 tile start, 1 source tile in LDS, 2 T done, 3 barrier, 4 G done, 5 barrier + X done, 6 barrier, 7 O done
 __device__ unsigned long long w4s_stamps[4096];
 #define W4S_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && 8 * tn + (k) < 4096) w4s_stamps[8 * tn + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else

@@ -57,7 +57,8 @@ enum W2xcKernelKind {
     W2XC_K_FIRST_SPLIT = 8,    // W2XC_K_FIRST storing d.out_terms term planes
     W2XC_K_LAST_GATHER = 9,    // sums the partial G planes of a fused W2XC_K_MID_SPLIT (out_terms = 9) into the output plane
     W2XC_K_FIRST2_SPLIT = 10,  // layers 1 (1 -> 32) and 2 (32 -> {32,64,128}) in one kernel; launched in layer 2's slot
-    W2XC_K_FUSED_AWAY = 11,    // layer 1 when W2XC_K_FIRST2_SPLIT computes it: no launch
+    W2XC_K_FUSED_AWAY = 11,    // layer 1 when W2XC_K_FIRST2_SPLIT / W2XC_K_FIRST2_WINO4 computes it: no launch
+    W2XC_K_FIRST2_WINO4 = 12,  // fp32: layers 1 (1 -> 32) and 2 (32 -> 32, Winograd F(4x4,3x3)) in one kernel (w2xc_first2_wino4.hip); launched in layer 2's slot
 };
 
 // Which kernel kind the fast path has for a (cin, cout) layer; W2XC_K_DIRECT when none.
@@ -83,6 +84,12 @@ hipError_t w2xc_launch_wino(const W2xcConvDesc &d, hipStream_t stream);
 bool w2xc_wino4_supported(int cin, int cout);
 void w2xc_wino4_pack(int cin, int cout, const float *w, float *dst);
 hipError_t w2xc_launch_wino4(const W2xcConvDesc &d, hipStream_t stream);
+// layers 1 + 2 of the fp32 path in one launch (w2xc_first2_wino4.hip): `in` / in_* / in_h / in_w / in_shift describe LAYER 1's one-plane input, off_y / off_x =
+// layer 1's offsets + layer 2's, w1pk / bias1 = layer 1's W2XC_K_FIRST image and bias; wpk = the w2xc_first2_wino4_pack image (36 * 32 * 32 floats), bias,
+// planar out, out_h / out_w / wino_py (first output row mod 4) = layer 2's region
+bool w2xc_first2_wino4_supported(int cin1, int cout1, int cout2);
+void w2xc_first2_wino4_pack(const float *w, float *dst);
+hipError_t w2xc_launch_first2_wino4(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer in conv3x3_wino4's epilogue; d.w7pk = w2xc_wino4_pack_last image, `out` = partial tap planes
 // G[64-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 64
 size_t w2xc_wino4_pack_last_floats(int cin);

@@ -624,6 +624,7 @@ const char *w2xc_kernel_name(W2xcKernelKind kind, int cin, int cout)
     case W2XC_K_LAST_GATHER: return "conv3x3_last_gather";
     case W2XC_K_FIRST2_SPLIT: return "conv3x3_first2_split";
     case W2XC_K_FUSED_AWAY: return "(in_next_layer)";
+    case W2XC_K_FIRST2_WINO4: return "conv3x3_first2_wino4";
     default: return "conv3x3_direct";
     }
 }
