@@ -40,6 +40,11 @@ for k, (cin, cout) in enumerate(PLANES, 1):
             sub = "conv3x3_first2_split<%d," % cout   # layers 1 + 2 in one kernel
         if k == NL and any("conv3x3_last_gather" in n for n in stats):
             sub = "conv3x3_last_gather"   # two-term modes: the last layer is fused into layer NL-1's epilogue + this gather
+    first2_fp32 = T == 0 and any("conv3x3_first2_wino4" in n for n in stats)
+    if first2_fp32 and k == 1:
+        continue                                       # computed inside layer 2's kernel (conv3x3_first2_wino4)
+    if first2_fp32 and k == 2:
+        sub = "conv3x3_first2_wino4"
     if T == 0 and k == NL and any("conv3x3_last_gather" in n for n in stats):
         sub = "conv3x3_last_gather"   # fp32: the last layer inside conv3x3_wino4's epilogue + this gather (w2xc_opts.fusion)
     names = [n for n in stats if sub in n and (n.startswith("void conv3x3") or n.startswith("conv3x3"))]
@@ -65,18 +70,22 @@ for k, (cin, cout) in enumerate(PLANES, 1):
         alg = ((PLANES[NL - 2][1] // (64 if w4 else 32) if T == 0 else 2) * 9 * 4 + 4) * px   # partial tap planes in (Cout / 64 or / 32 blocks, or two halves), one plane out
     if fused_fp32 and k == NL - 1:
         alg = (cin * 4 + (cout // (64 if w4 else 32)) * 9 * 4) * px     # fused: writes the partial tap planes instead of cout fp32 planes
+    if first2_fp32 and k == 2:
+        alg = (4 + cout * 4) * px                       # reads the one-plane input, layer 1's activations never reach HBM
     if T > 0 and k == 2 and any("conv3x3_first2_split" in n for n in stats):
         alg = (4 + cout * out_bpe) * px                 # reads the input plane, layer 1's activations never reach HBM
     if T > 0 and k == NL - 1 and any("conv3x3_last_gather" in n for n in stats):
         alg = (cin * in_bpe + 2 * 9 * 4) * px           # fused: writes the partial tap planes instead of cout fp32 planes
     wino = "conv3x3_wino" in name
-    issued = 0.25 if "conv3x3_wino4" in name else 16.0 / 36.0 if wino else 1.0   # F(4x4,3x3): 36 of 144 multiplies; F(2x2,3x3): 16 of 36
+    issued = 0.25 if ("conv3x3_wino4" in name or "first2_wino4" in name) else 16.0 / 36.0 if wino else 1.0   # F(4x4,3x3): 36 of 144 multiplies; F(2x2,3x3): 16 of 36
     e = {"layer": k, "avg_ns": avg_ns, "calls": int(stats[name]["Calls"]), "pixels": px, "executed_flops_over_algorithmic": issued,
          "algorithmic_flops": 18 * cin * cout * px, "algorithmic_tflops": 18 * cin * cout * px / avg_ns / 1e3,
          "tflops": 18 * cin * cout * px / avg_ns / 1e3 * issued,   # FLOPs the kernel issues / time
          "mfma_products_per_fma": PRODUCTS if 1 < k < NL else 1,
          "algorithmic_bytes": alg, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_traffic_bytes": rd + wr,
          "traffic_over_algorithmic": (rd + wr) / alg, "achieved_GBps_algorithmic": alg / avg_ns}
+    if sub == "conv3x3_first2_wino4":
+        e["note"] = "layers 1 + 2 in one launch: layer 1 (18 FLOP per value, 576 per pixel) runs on the VALU inside this kernel and is not in the FLOP figures, which are layer 2's"
     if sub == "conv3x3_last_gather":   # the last layer's MFMA work runs inside layer NL-1's kernel; this kernel only adds 18 floats per pixel
         e["algorithmic_flops"] = 18 * px
         e["tflops"] = e["algorithmic_tflops"] = 18 * px / avg_ns / 1e3

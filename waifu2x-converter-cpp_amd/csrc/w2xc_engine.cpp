@@ -710,6 +710,14 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
             band = (total + nb - 1) / nb;   // equalise (never larger than the band that was just checked)
         }
     }
+    if (fuse_first_fp32(m, o)) {
+        // conv3x3_first2_wino4 addresses its 32 output planes with 32-bit lane offsets (12 plane strides + a row): planes of at most 64 Mi floats
+        const size_t wk = ((size_t)w + 2 * (n - 2) + 31) & ~(size_t)31;
+        const size_t max_rows = ((size_t)64 << 20) / wk;
+        const size_t halo = HL == 1 ? 2 * (size_t)(n - 2) : 6 + 8 * (size_t)(n - 2);
+        if (max_rows < halo + 8) return fail(W2XC_ERR_UNSUPPORTED, "plane too wide (%d pixels) for the fused first layers; use w2xc_opts.fusion = W2XC_FUSION_OFF", w);
+        if ((size_t)band + halo > max_rows) band = (int)(max_rows - halo);
+    }
     if (HL > 1 && band < total) band = std::max(4, band & ~3);   // (band edges on block rows: no rounding-out rows)
     band = std::min(band, total);
     {
