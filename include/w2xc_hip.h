@@ -90,11 +90,12 @@ typedef struct w2xc_opts {
                                * promises they are unmodified, and the copy still on the device is used instead of
                                * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
                                * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
-    int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path (the one-plane last layer inside the epilogue
-                               * of the layer before it, convertRoutine.cpp:66-76's loop collapsed by one launch).  The default
-                               * kernel conv3x3_wino4 carries the epilogue: W2XC_FUSION_AUTO = on,
-                               * W2XC_FUSION_OFF runs conv3x3_last as its own launch.  Results stay inside the fp32 gate either way
-                               * (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
+    int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path -- convertRoutine.cpp:66-76's loop collapsed by two launches:
+                               * (a) the one-plane last layer inside the epilogue of the layer before it (the default kernel conv3x3_wino4
+                               *     carries it; conv3x3_last_gather finishes), (b) layers 1 (1 -> 32) and 2 (32 -> 32) in one launch,
+                               *     conv3x3_first2_wino4: layer 1's activations never reach HBM.  W2XC_FUSION_AUTO = both on where the
+                               *     model's shapes allow, W2XC_FUSION_OFF runs every layer as its own launch.  Results stay inside the
+                               *     fp32 gate either way (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
                                * (The 16-bit modes: environment W2XC_SPLIT_FUSE_FIRST / _LAST.) */
     int      host_units;      /* host-pointer entry points, test aid: cut the rows into this many units, round-robin over the selected
                                * devices, so a one-GPU box runs the multi-device arithmetic; 0 = one unit per device              */

@@ -456,10 +456,11 @@ bool uses_wino4(const w2xc_model *m, const w2xc_opts &o)
     return false;
 }
 // conv3x3_wino4 reads PLANAR activations (one plane per channel, rows of roundup32(w) floats: 16-byte aligned pixel quads, tiles on 128-byte lines)
-// -- except with 32 input planes, where it reads the NHWC pixels (one 128-byte line each) that the 32-plane producers conv3x3_first / conv3x3_wino
-// write.  Layer l's output (l = 0 .. n-2) is planar when its consumer is a conv3x3_wino4 layer with 64 / 128 input planes, or when layer l is a
-// conv3x3_wino4 layer and its consumer is conv3x3_direct (any strides); everything else stays NHWC (conv3x3_wino4 writes either).  Producers that
-// write planar: conv3x3_wino4, conv3x3_first (3 -> 64 / 128), conv3x3_direct.
+// -- with 32 input planes also the NHWC pixels (one 128-byte line each) that the 32-plane producers conv3x3_first / conv3x3_wino write.
+// Layer l's output (l = 0 .. n-2) is planar when its consumer is a conv3x3_wino4 layer with 64 / 128 input planes, when layer l is the fused
+// conv3x3_first2_wino4 launch (layers 1 + 2; its consumer conv3x3_wino4<32, .> then reads planar), or when layer l is a conv3x3_wino4 layer and its
+// consumer is conv3x3_direct (any strides); everything else stays NHWC (conv3x3_wino4 writes either).  Producers that write planar:
+// conv3x3_wino4, conv3x3_first2_wino4, conv3x3_first (3 -> 64 / 128), conv3x3_direct.
 bool is_wino4_layer(const w2xc_model *m, int l, const w2xc_opts &o)
 {
     if (split_terms(o) != 0 || o.precision != W2XC_PRECISION_FP32 || o.kernel == W2XC_KERNEL_DIRECT) return false;
@@ -880,9 +881,21 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 const int RL = d.out_h, R = y1 - y0;
                 // three producer launches -- 1/2, then 5/16, then the rest -- of whole 16-row tiles: every launch of the persistent kernel has a ramp and a tail
                 // (measured: four equal chunks cost layer 6 +0.6 ms on the 2160x3840 frame), while what the LAST chunk writes cannot hide behind compute
+                // ... and a launch whose item count is not a multiple of the 256 persistent workgroups ends with a partly filled round: among the tile-row
+                // counts within 8 of the wanted one, take the one that wastes the fewest workgroup slots (2160x3840, two 64-plane blocks: 64 + 48 + 24
+                // tile rows = 60 + 45 + 22.5 rounds against 63.75 + 40.3 + 23.4 for exact halves)
+                const int items_per_row = ((d.out_w + 31) / 32) * std::max(1, hl.nout / 64);
+                auto chunk_rows = [&](int want) {
+                    int best = std::max(4, (want + 15) / 16), waste = 1 << 30;
+                    for (int r = std::max(4, (want + 15) / 16 - 8); r <= (want + 15) / 16 + 8; r++) {
+                        const int items = items_per_row * r, w_ = ((items + 255) / 256) * 256 - items;
+                        if (w_ < waste || (w_ == waste && std::abs(r * 16 - want) < std::abs(best * 16 - want))) { waste = w_; best = r; }
+                    }
+                    return best * 16;
+                };
                 for (int p0 = 0, o0 = 0, ci = 0; p0 < RL; ci++) {
                     const int want = ci == 0 ? RL / 2 : ci == 1 ? (RL * 5) / 16 : RL;
-                    int p1 = std::min(RL, p0 + std::max(64, (want + 15) & ~15));
+                    int p1 = ci < 2 ? std::min(RL, p0 + chunk_rows(want)) : RL;
                     if (RL - p1 < 64) p1 = RL;
                     W2xcConvDesc dd = d;
                     dd.out_h = p1 - p0;
@@ -891,11 +904,11 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                     int rc = launch_layer(c, m, k - 1, kind, dd, st, o);
                     if (rc) return rc;
                     const int o1 = p1 == RL ? R : std::min(R, std::max(o0, p1 - off_l - 2));   // output rows whose three input rows exist
-                    // the LAST chunk's rows in pieces of ~128: what nothing can hide is then the download + stitch of the last piece only
+                    // the LAST chunk's rows in pieces of ~128, its last 128 in pieces of 64: what nothing can hide is then the download + stitch of the last piece only
                     const int piece = (p1 == RL && o1 - o0 > 192) ? 128 : std::max(o1 - o0, 1);
                     for (int a = o0; a < o1;) {
-                        int b = std::min(o1, a + piece);
-                        if (o1 - b < 64) b = o1;
+                        int b = std::min(o1, a + ((p1 == RL && o1 - a <= 160 && o1 - a > 96) ? 64 : piece));
+                        if (o1 - b < 48) b = o1;
                         W2xcConvDesc dg = dl;
                         dg.out_h = b - a;
                         dg.off_y = off_l + a;

@@ -15,7 +15,7 @@
 //               (main.cpp:132-140, in_shift) folded into the addresses, exactly as conv3x3_first does.
 //   T           per lane two patches (block, channel c) and (block, c + 16): the 6 x 6 layer-1 activations leaky(b1[c] + sum w1[c][tap] src) as a
 //               bias-first fma chain in tap order over an 8 x 8 window (rolling three rows), then V = B^T d B, written to LDS in B-fragment order
-//               V[xi][k-step / 4][lane = 16 k + block][k-step % 4]: wave g handles the channels = g mod 4, so its 64 lanes hit 64 banks.
+//               V[xi][k-step / 4][lane = 16 k + block][k-step % 4]: wave g handles the channels = g mod 4 with a lane map of its own (conflict-free dword writes).
 //   G           36 x (32 planes x 16 blocks x 32 channels) GEMMs: per wave 9 xi x 2 plane tiles x 8 k-steps = 144 MFMAs, one ds_read_b128 per
 //               (xi, four k-steps); every V value is read by exactly one wave.
 //   X           the accumulators change owner through LDS (over V): M[xi][plane pair][lane = 16 (plane quad) + block] as 8-byte pairs.
@@ -127,13 +127,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_first2_wino4(W2xcConvDesc d, i
         W4S_STAMP(1);
         // ================= T: layer 1 on the fly + input transform -> V: patches (block n, channel wave + 4 hi) and (block n, + 16) =================
         {
-            const float *sw = lds + SRC_FLOATS + (4 * r) * SW + 4 * c8;   // the lane's 8 x 8 window: rows 4 r + (0..7), columns 4 c8 + (0..7)
-            float *vb = lds + ((16 * wave + n) * 4 + hi);                  // + ((xi * 2 + p) * 64) * 4 floats
-            const bool edge = tx * 32 + 34 > in_w2;                        // (wave-uniform: the tile touches the right edge of layer 2's input)
-            const int lim = in_w2 - (tx * 32 + 4 * c8);                    // patch columns >= lim are outside it: zero
+            // T's own lane map: block column in bits 0-2, channel step in bits 3-4, block row in bit 5 -- a ds_write_b32 is served in two groups of 32
+            // lanes over 32 banks, and lanes 0-31 = (8 block columns x 4 channel steps) write the dwords 4 column + step: 32 banks, no conflict
+            // (with the MFMA-side map block = lane & 15 the blocks n and n + 8 of a group share their banks: 30 % of the kernel's LDS cycles)
+            const int tc8 = lane & 7, thi = (lane >> 3) & 3, tr = lane >> 5, tnn = 8 * tr + tc8;
+            const float *sw = lds + SRC_FLOATS + (4 * tr) * SW + 4 * tc8;   // the lane's 8 x 8 window: rows 4 r + (0..7), columns 4 c8 + (0..7)
+            float *vb = lds + ((16 * wave + tnn) * 4 + thi);                // + ((xi * 2 + p) * 64) * 4 floats
+            const bool edge = tx * 32 + 34 > in_w2;                         // (wave-uniform: the tile touches the right edge of layer 2's input)
+            const int lim = in_w2 - (tx * 32 + 4 * tc8);                    // patch columns >= lim are outside it: zero
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const int c = wave + 4 * (4 * p + hi);
+                const int c = wave + 4 * (4 * p + thi);
                 float w1[9];
                 const f32x4 wa = *reinterpret_cast<const f32x4 *>(lds + W1_FLOATS + c * 12), wb = *reinterpret_cast<const f32x4 *>(lds + W1_FLOATS + c * 12 + 4),
                             wc = *reinterpret_cast<const f32x4 *>(lds + W1_FLOATS + c * 12 + 8);
