@@ -346,7 +346,7 @@ def test_weight_statistics_fp32_and_fp16x2(gpu, init, amp):
     # every fp32 mid-layer kernel against the fp64 truth, side by side, each with its OWN stated margin over the CPU oracle's error
     # (the oracle sums per-plane partials, the direct MFMA kernel is one k-ordered fma chain, Winograd sums transformed products:
     # three fp32 summation orders of the same arithmetic).  FP64_MARGIN = 2x the worst ratio measured in round 3 (printed below).
-    for name, kern in (("winograd4 (conv3x3_wino4, the default, + conv3x3_wino for 32 output planes)", gpu.KERNEL_WINOGRAD4),
+    for name, kern in (("winograd4 (the default: conv3x3_first2_wino4 + conv3x3_wino4)", gpu.KERNEL_WINOGRAD4),
                        ("winograd32 (conv3x3_wino)", gpu.KERNEL_WINOGRAD32), ("direct mfma (conv3x3_mfma2)", gpu.KERNEL_MFMA)):
         g = got if kern is None else ms.convert(x, opts=gpu.make_opts(kernel=kern))
         e_gpu = float(np.abs(g - truth).max())

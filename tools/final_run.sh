@@ -10,4 +10,4 @@ cp gpurun_out/r5_roofline.json profiles/r5_roofline.json
 cp gpurun_out/r5_bf16_roofline.json profiles/r5_bf16_roofline.json
 python bench.py > gpurun_out/r5_bench_fp32.json 2> gpurun_out/bench_fp32.err; tail -c 900 gpurun_out/r5_bench_fp32.json
 python bench.py --precision bf16 --no-cpu-baseline > gpurun_out/r5_bench_bf16.json 2> gpurun_out/bench_bf16.err; tail -c 700 gpurun_out/r5_bench_bf16.json
-python tools/run_configs.py > gpurun_out/r5_configs.json 2> gpurun_out/configs.err; tail -c 600 gpurun_out/r5_configs.json
+python tools/run_configs.py > gpurun_out/configs.log 2> gpurun_out/configs.err; cp gpurun_out/configs.json gpurun_out/r5_configs.json; tail -c 600 gpurun_out/configs.log
