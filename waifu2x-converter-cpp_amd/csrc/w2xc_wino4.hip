@@ -101,6 +101,7 @@ static __device__ __forceinline__ void at6(float m0, float m1, float m2, float m
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte global access on a dword-aligned address
 
 // position (i, j) of the transformed domain in the fragment order: the column halves j < 3 / j >= 3 as the xi ranges [0, 18) / [18, 36)
 static constexpr __host__ __device__ int xi_of(int i, int j) { return j < 3 ? 3 * i + j : 18 + 3 * i + (j - 3); }
@@ -536,27 +537,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 for (int e = 0; e < 4; e++) a7[e] = w7[e * 64];
             }
             char *red = ldsb + V_BASE + V_BYTES;   // (V slot 1: idle until the next item's first stage writes V of its second)
-            // [pt][tap quad 0 / 1][128 pixels][4] (16 KiB) + [pt][128 pixels] for tap 8 (2 KiB)
-            // Two output ROWS of the block at a time (the row transform of a column per row PAIR: 7 operations instead of 10 for all four rows):
-            // 48 + 16 live values beside the 144 accumulators.
+            // [pt][tap][128 pixels] floats (18 KiB)
+            // The row transform A^T M of every column, all four rows at once (10 operations per column and plane; two passes over row PAIRS recompute
+            // the four sums and differences: 14): the six accumulators of a (column, plane) are dead behind it, their registers hold its four results.
+            float tm[4][6][4];   // [row][column j][plane e]
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const float m0 = acc[xi_of(0, j)][e], m1 = acc[xi_of(1, j)][e], m2 = acc[xi_of(2, j)][e], m3 = acc[xi_of(3, j)][e],
+                                m4 = acc[xi_of(4, j)][e], m5 = acc[xi_of(5, j)][e];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    tm[0][j][e] = m0 + s1 + s2;
+                    tm[1][j][e] = __builtin_fmaf(1.5f, d2, 0.75f * d1);
+                    tm[2][j][e] = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
+                    tm[3][j][e] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
+                }
 #pragma unroll
             for (int rp = 0; rp < 2; rp++) {
-                float tm[2][6][4];   // [row of the pair][column j][plane e]
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const float m0 = acc[xi_of(0, j)][e], m1 = acc[xi_of(1, j)][e], m2 = acc[xi_of(2, j)][e], m3 = acc[xi_of(3, j)][e],
-                                    m4 = acc[xi_of(4, j)][e], m5 = acc[xi_of(5, j)][e];
-                        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                        if (rp == 0) {
-                            tm[0][j][e] = m0 + s1 + s2;
-                            tm[1][j][e] = __builtin_fmaf(1.5f, d2, 0.75f * d1);
-                        } else {
-                            tm[0][j][e] = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
-                            tm[1][j][e] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
-                        }
-                    }
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
                     const int i = 2 * rp + rr;
@@ -564,7 +562,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float y0, y1, y2, y3;
-                        at6(tm[rr][0][e], tm[rr][1][e], tm[rr][2][e], tm[rr][3][e], tm[rr][4][e], tm[rr][5][e], y0, y1, y2, y3);
+                        at6(tm[i][0][e], tm[i][1][e], tm[i][2][e], tm[i][3][e], tm[i][4][e], tm[i][5][e], y0, y1, y2, y3);
                         const float w0 = y0 + bq[e], w1 = y1 + bq[e], w2 = y2 + bq[e], w3 = y3 + bq[e];
                         const float l0 = __builtin_amdgcn_fmed3f(w0, 0.1f * w0, 3.402823466e+38f), l1 = __builtin_amdgcn_fmed3f(w1, 0.1f * w1, 3.402823466e+38f);
                         const float l2 = __builtin_amdgcn_fmed3f(w2, 0.1f * w2, 3.402823466e+38f), l3 = __builtin_amdgcn_fmed3f(w3, 0.1f * w3, 3.402823466e+38f);
@@ -580,38 +578,35 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         for (int e = 0; e < 4; e++)
 #pragma unroll
                             for (int j = 0; j < 4; j++) D[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a7[e], y[e][j], D[j], 0, 0, 0);
-                        // lane (k, t) holds taps 4 k .. 4 k + 3 of pixel j of block t: pixel index p = (block row) * 32 + (block column) * 4 + j of the row slab
+                        // lane (k, t) holds taps 4 k .. 4 k + 3 of pixel j of block t.  The slab is [pt][tap][128 pixels] (pixel index p = (block row) * 32 +
+                        // (block column) * 4 + j): ONE 16-byte write per tap = the four pixels of this lane's block, eight lanes = 128 contiguous bytes (as
+                        // [pt][tap quad][pixel][4] the eight lanes of a write group sat 64 bytes apart: four-way bank conflicts, 9 % of layer 6's LDS cycles)
                         const int p0 = (2 * bt + (t >> 3)) * 32 + (t & 7) * 4;
                         if (k < 2) {
 #pragma unroll
-                            for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4 *>(red + ((pt * 2 + k) * 128 + p0 + j) * 16) = D[j];
+                            for (int r = 0; r < 4; r++) *reinterpret_cast<f32x4 *>(red + ((pt * 9 + 4 * k + r) * 128 + p0) * 4) = f32x4{D[0][r], D[1][r], D[2][r], D[3][r]};
                         } else if (k == 2) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) *reinterpret_cast<float *>(red + 16384 + (pt * 128 + p0 + j) * 4) = D[j][0];
+                            *reinterpret_cast<f32x4 *>(red + ((pt * 9 + 8) * 128 + p0) * 4) = f32x4{D[0][0], D[1][0], D[2][0], D[3][0]};
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                         {
                             const int tid = wave * 64 + lane_e;
-                            if (tid < 384) {
-                                const int p = tid & 127, kq = tid >> 7;     // kq = 0, 1: taps 4 kq .. 4 kq + 3; kq = 2: tap 8
+                            if (tid < 288) {
+                                const int tap = tid >> 5, p = (tid & 31) * 4;     // nine taps x 32 pixel quads
                                 const int gy = ty0 + 4 * (p >> 5) + i, gx = tile_x * 32 + (p & 31);
-                                const bool ok = gy >= 0 && gy < d.out_h && gx < d.out_w;
-                                float *g = d.out + (long long)ob * d.out_ts + (long long)gy * d.out_rs + gx;
-                                if (kq < 2) {
-                                    f32x4 sum = *reinterpret_cast<const f32x4 *>(red + ((0 * 2 + kq) * 128 + p) * 16);
+                                f32x4 sum = *reinterpret_cast<const f32x4 *>(red + ((0 * 9 + tap) * 128 + p) * 4);
 #pragma unroll
-                                    for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const f32x4 *>(red + ((q * 2 + kq) * 128 + p) * 16);   // (fixed order: reproducible)
-                                    if (ok) {
+                                for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const f32x4 *>(red + ((q * 9 + tap) * 128 + p) * 4);   // (fixed order: reproducible)
+                                if (gy >= 0 && gy < d.out_h && gx < d.out_w) {
+                                    float *g = d.out + (long long)ob * d.out_ts + (long long)tap * d.out_gs + (long long)gy * d.out_rs + gx;
+                                    if (gx + 3 < d.out_w) *reinterpret_cast<f32x4u *>(g) = sum;   // (dword-aligned: rows of out_w floats)
+                                    else {
 #pragma unroll
-                                        for (int r = 0; r < 4; r++) g[(long long)(4 * kq + r) * d.out_gs] = sum[r];
+                                        for (int e = 0; e < 3; e++)
+                                            if (gx + e < d.out_w) g[e] = sum[e];
                                     }
-                                } else {
-                                    float sum = *reinterpret_cast<const float *>(red + 16384 + p * 4);
-#pragma unroll
-                                    for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const float *>(red + 16384 + (q * 128 + p) * 4);
-                                    if (ok) g[8 * d.out_gs] = sum;
                                 }
                             }
                         }
