@@ -99,6 +99,57 @@ def test_wino4_matrices_are_the_cook_toom_matrices_of_their_points(w2xc):
     assert np.abs(U - expect).max() <= 2.0 ** -23 * np.abs(expect).max()
 
 
+# ---- conv3x3_first2_wino4 (w2xc_first2_wino4.hip): layer 2's register-stationary weight image, and layers 1 + 2 together ----
+def _pack_first2(w2xc, w):
+    lib = ctypes.CDLL(w2xc.LIB_PATH)
+    fn = getattr(lib, "_Z22w2xc_first2_wino4_packPKfPf")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    dst = np.zeros(36 * 32 * 32, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    fn(w.ctypes.data, dst.ctypes.data)
+    return dst
+
+
+def _unpack_first2(img):
+    """U[xi = 6 i + j][plane][channel] from [wave g][xi - 9 g][pt][ks][lane = 16 k + o] = U_xi[16 pt + o][4 ks + k] (w2xc_first2_wino4_pack's comment)."""
+    a = img.reshape(4, 9, 2, 8, 4, 16)                  # g, xl, pt, ks, k, o
+    a = a.transpose(0, 1, 2, 5, 3, 4)                   # g, xl, pt, o, ks, k
+    return a.reshape(36, 32, 32)
+
+
+def test_first2_wino4_weight_image_and_both_layers(w2xc):
+    """the fused first two layers as the kernel evaluates them -- layer 1 as a bias-first sum over its nine taps + LeakyReLU on every 6x6 patch value, layer 2 as
+    Y = A^T [ sum_c U (.) (B^T d B) ] A from the library's own weight image -- against the two 3x3 correlations of modelHandler.cpp:127-152, in float64."""
+    rng = np.random.default_rng(2025)
+    w1 = (rng.standard_normal((32, 1, 3, 3)) * 0.5).astype(np.float32)
+    b1 = rng.uniform(-0.05, 0.05, 32)
+    w2 = (rng.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32)
+    U = _unpack_first2(_pack_first2(w2xc, w2)).astype(np.float64)
+    assert np.isfinite(U).all() and np.abs(U).max() > 0
+    src = rng.random((8, 8))                                                # the 8 x 8 source window of one 4x4 output block
+    leaky = lambda v: np.maximum(v, 0.1 * v)
+    d = np.zeros((32, 6, 6))
+    for ky in range(3):
+        for kx in range(3):
+            d += w1[:, 0, ky, kx].astype(np.float64)[:, None, None] * src[None, ky:ky + 6, kx:kx + 6]
+    d = leaky(d + b1[:, None, None])                                        # layer 1 on the patch
+    V = np.einsum("ia,cab,jb->cij", BT, d, BT).reshape(32, 36)
+    M = np.einsum("xpc,cx->px", U, V).reshape(32, 6, 6)
+    Y = np.einsum("ia,pab,jb->pij", AT, M, AT)
+    ref = np.zeros((32, 4, 4))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum("pc,cyx->pyx", w2[:, :, ky, kx].astype(np.float64), d[:, ky:ky + 4, kx:kx + 4])
+    assert np.abs(Y - ref).max() <= 1e-5 * np.abs(ref).max(), (np.abs(Y - ref).max(), np.abs(ref).max())
+    # the image is a permutation of G g G^T: one plane, one channel
+    w = np.zeros((32, 32, 3, 3), np.float32)
+    g = rng.standard_normal(3).astype(np.float32)
+    w[17, 5] = np.outer(g, g)
+    Ug = _unpack_first2(_pack_first2(w2xc, w))
+    assert np.count_nonzero(Ug) == np.count_nonzero(Ug[:, 17, 5]) > 0          # nothing lands on another (plane, channel)
+
+
 # ---- the fp32 error of F(4x4,3x3) as the kernel orders it, emulated in numpy float32 ----
 def _bt6_f32(x0, x1, x2, x3, x4, x5):
     """bt6 of w2xc_wino4.hip on float32 arrays (numpy rounds the product and the sum separately where the kernel's fma rounds once: an upper bound)."""
