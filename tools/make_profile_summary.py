@@ -18,7 +18,8 @@ PLANES = [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 1)
 shutil.copy(base + "trace/trace_kernel_stats.csv", prefix + "_kernel_stats.csv")
 here = os.path.dirname(os.path.abspath(__file__))
 pmcs = [base + d + "/pmc_counter_collection.csv" for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds")]
-open(prefix + "_pmc_summary.txt", "w").write(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py")] + pmcs, capture_output=True, text=True).stdout)
+extra = [base + d + "/pmc_counter_collection.csv" for d in ("pmc_issue", "pmc_fifo") if os.path.exists(base + d + "/pmc_counter_collection.csv")]
+open(prefix + "_pmc_summary.txt", "w").write(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py")] + pmcs + extra, capture_output=True, text=True).stdout)
 
 def mean_counter(path, sub, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if sub in r["Kernel_Name"] and r["Counter_Name"] == counter]
