@@ -110,6 +110,24 @@ def pmc_traffic(kernel, cin, cout, H, W, precision="fp32"):
     return None, "no matching kernel in " + rel
 
 
+def probe_matrix_clock(lib_path, device, ms=30):
+    """What this box's matrix pipes run at: libw2xc_probe.so (csrc/w2xc_probe.hip, a measurement aid beside the drop-in library) streams
+    independent v_mfma_f32_16x16x4_f32 on every SIMD for ~`ms` ms; MHz = MFMAs per SIMD per second x 32 cycles.  None when the
+    probe library is not there (it is never needed by the product path)."""
+    import ctypes
+    path = os.path.join(os.path.dirname(lib_path), "libw2xc_probe.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.w2xc_probe_mfma_mhz.restype = ctypes.c_double
+        lib.w2xc_probe_mfma_mhz.argtypes = [ctypes.c_int, ctypes.c_int]
+        mhz = float(lib.w2xc_probe_mfma_mhz(int(device), int(ms)))
+    except (OSError, AttributeError):
+        return None
+    return round(mhz, 1) if mhz > 0 else None
+
+
 def cpu_baseline(layers, plane, budget_s=15.0):
     """Time the CPU oracle ("port": restatement of the reference algorithm, oracle/w2xc_oracle.c -- the
     real binary needs OpenCV, which is absent) on whole 512x512 blocks of the same plane.
@@ -634,6 +652,12 @@ def main():
         if host:
             out["host_to_host"] = host
         out.update(extras)
+        mhz = probe_matrix_clock(w2xc.LIB_PATH, dev_index)
+        if mhz:
+            # gpurun boxes differ by up to 30 % on the same launch: what THIS box's matrix pipes deliver under an all-SIMD MFMA stream, beside the
+            # nominal clock `roofline.peak` is priced at (the fraction itself stays at the nominal peak)
+            out["matrix_clock"] = {"mfma_equiv_mhz": mhz, "nominal_mhz": 2400.0, "ratio": round(mhz / 2400.0, 4),
+                                   "how": "libw2xc_probe.so: 30 ms of independent v_mfma_f32_16x16x4_f32 on every SIMD, MFMAs/s/SIMD x 32 cycles, after the timed passes"}
         zl = extras.get("zero_operand_ms_per_step", {}).get("layers_ms")
         if zl and zl[dom] > 0 and bands == 1:
             # the dominant kernel at the clock an idle datapath gets: what the schedule alone achieves (tools/power_probe.py)

@@ -233,18 +233,35 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     // B = V at V_BASE + slot * V_BYTES + bt * 1024 + (xi / 4) * 2048.  ONE lane-linear VGPR (b_voff) + SGPR bases: the copies the compiler would
     // otherwise keep per base cost registers this kernel does not have.
     const unsigned ua_u = U_BASE + (unsigned)pt * 1024u, va_u = V_BASE + (unsigned)bt * 1024u;
+#ifndef W4_KEEP_BASES
+#define W4_KEEP_BASES 1   // 1: the operand base addresses (U slot 0 / 1, V) live in three registers of their own; 0: rebuilt from the lane register where used
+#endif
+    // The operand bases of a stage: with W4_KEEP_BASES they are three more lane-linear registers that live through the kernel (a ds_read's 16-bit immediate
+    // reaches both V slots from one base, U's two slots need one each); rebuilt per use they were 7 VALU instructions per wave and stage -- and a VALU
+    // instruction is 4 cycles of a SIMD that issues nothing else meanwhile
+    unsigned ua0_v = b_voff + ua_u, ua1_v = b_voff + ua_u + U_BYTES, va_v = b_voff + va_u;
+    asm volatile("" : "+v"(ua0_v), "+v"(ua1_v), "+v"(va_v));
+    auto ua_of = [&](unsigned slot) { return W4_KEEP_BASES ? ldsb + (slot ? ua1_v : ua0_v) : ldsb + (lin() + (ua_u + slot * U_BYTES)); };
+    auto va_of = [&](unsigned slot) { return W4_KEEP_BASES ? ldsb + va_v + slot * V_BYTES : ldsb + (lin() + (va_u + slot * V_BYTES)); };
     // transformer lane (r, kk, c) = block (block row 2 bt + r, column c), channel kk: patch row i, columns 0..3 = chunk (kk, 4 (2 bt + r) + i, c),
     // columns 4, 5 = the first half of chunk (kk, same row, c + 1)
-    auto tr_rd = [&]() {
+#ifndef W4_KEEP_TR
+#define W4_KEEP_TR 1   // 1: the transform's patch-read and V-write lane offsets live in two registers of their own (0: rebuilt from the lane register per quarter)
+#endif
+    auto tr_rd_calc = [&]() {
         const int l = lane_o(), tr_r = l >> 5, tr_k = (l >> 3) & 3, tr_c = l & 7;
         return IN_NHWC ? (unsigned)((4 * (2 * bt + tr_r) * 36 + tr_c) * 16 + tr_k * 4)                // + buffer + (i * 36 + (j & 3) * 9 + (j >> 2)) * 16
                        : (unsigned)((tr_k * CHS + 4 * (2 * bt + tr_r) * 9 + tr_c) * 16);        // + buffer + i * 144 (+ 16)
     };
     // V-slot address of this lane's patch in the fragment order lane = 16 kk + block (+ slot * V_BYTES + (xi / 4) * 2048)
-    auto tr_wr = [&]() {
+    auto tr_wr_calc = [&]() {
         const int l = lane_o(), tr_r = l >> 5, tr_k = (l >> 3) & 3, tr_c = l & 7;
         return V_BASE + (unsigned)bt * 1024u + (unsigned)((tr_k * 16 + tr_r * 8 + tr_c) * 16);
     };
+    unsigned tr_rd_v = tr_rd_calc(), tr_wr_v = tr_wr_calc();
+    asm volatile("" : "+v"(tr_rd_v), "+v"(tr_wr_v));
+    auto tr_rd = [&]() { return W4_KEEP_TR ? tr_rd_v : tr_rd_calc(); };
+    auto tr_wr = [&]() { return W4_KEEP_TR ? tr_wr_v : tr_wr_calc(); };
 
     // The input transform V = B^T d B of a patch set (16 blocks x 4 channels = one patch per lane) by ONE wave in FOUR QUARTERS over four consecutive
     // stages, the 36 values in REGISTERS in between:
@@ -388,8 +405,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     // register buffer of operand group g of a stage of parity par: g mod 3 with two groups of look-ahead; with one, two buffers whose roles swap with the
     // stage's parity (group 8 and the next stage's group 0 are alive together)
     auto load_first = [&](unsigned slot) {
-        const char *ua = ldsb + (lin() + (ua_u + slot * U_BYTES));
-        const char *va = ldsb + (lin() + (va_u + slot * V_BYTES));
+        const char *ua = ua_of(slot);
+        const char *va = va_of(slot);
         static_for<0, PF>([&](auto G) {
             constexpr int g = decltype(G)::value;
             const int b = PF == 2 ? g : (int)slot;
@@ -413,8 +430,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             constexpr unsigned par = J & 1, nxt = par ^ 1u;                               // U / V slot of this stage and of the next
             int u_ob = item % NOB, u_s = s + 1;
             if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
-            const char *ua = ldsb + (lin() + (ua_u + par * U_BYTES));
-            const char *va = ldsb + (lin() + (va_u + par * V_BYTES));
+            const char *ua = ua_of(par);
+            const char *va = va_of(par);
             const char *srcQ = nullptr;
             char *dstQ = nullptr;
             if constexpr (QT == 0) srcQ = ldsb + (rd + tr_rd());
@@ -443,8 +460,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     if (s != NST - 1) {                     // (an item's last stage: the epilogue comes first, the item loop reads them)
                         if constexpr (PF == 2) load_first(nxt);
                         else {
-                            a4[nxt] = *reinterpret_cast<const f32x4 *>(ldsb + (lin() + (ua_u + nxt * U_BYTES)));
-                            b4[nxt] = *reinterpret_cast<const f32x4 *>(ldsb + (lin() + (va_u + nxt * V_BYTES)));
+                            a4[nxt] = *reinterpret_cast<const f32x4 *>(ua_of(nxt));
+                            b4[nxt] = *reinterpret_cast<const f32x4 *>(va_of(nxt));
                         }
                     }
                     W4_STAMP(stamp++);
