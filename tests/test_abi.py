@@ -34,6 +34,15 @@ def test_library_exports_every_declared_symbol(w2xc):
     assert b"gfx950" in lib.w2xc_version()
 
 
+def test_probe_library_is_separate_from_the_drop_in(w2xc):
+    """bench.py's matrix-clock probe (csrc/w2xc_probe.hip) is a library of its own: libw2xc_hip.so carries no probe symbol,
+    libw2xc_probe.so exports exactly the one entry point bench.py binds"""
+    probe = os.path.join(os.path.dirname(w2xc.LIB_PATH), "libw2xc_probe.so")
+    assert os.path.exists(probe), "make -C waifu2x-converter-cpp_amd/csrc builds it beside libw2xc_hip.so"
+    assert hasattr(C.CDLL(probe), "w2xc_probe_mfma_mhz")
+    assert not hasattr(C.CDLL(w2xc.LIB_PATH), "w2xc_probe_mfma_mhz")
+
+
 def test_no_oracle_in_product_path():
     """the product package must never import, link or execute anything under oracle/"""
     pkg = os.path.join(ROOT, "waifu2x-converter-cpp_amd")
