@@ -657,7 +657,7 @@ def main():
             # gpurun boxes differ by up to 30 % on the same launch: what THIS box's matrix pipes deliver under an all-SIMD MFMA stream, beside the
             # nominal clock `roofline.peak` is priced at (the fraction itself stays at the nominal peak)
             out["matrix_clock"] = {"mfma_equiv_mhz": mhz, "nominal_mhz": 2400.0, "ratio": round(mhz / 2400.0, 4),
-                                   "how": "libw2xc_probe.so: 30 ms of independent v_mfma_f32_16x16x4_f32 on every SIMD, MFMAs/s/SIMD x 32 cycles, after the timed passes"}
+                                   "how": "libw2xc_probe.so: 30 ms of independent v_mfma_f32_16x16x4_f32 on random operands on every SIMD, MFMAs/s/SIMD x 32 cycles, after the timed passes"}
         zl = extras.get("zero_operand_ms_per_step", {}).get("layers_ms")
         if zl and zl[dom] > 0 and bands == 1:
             # the dominant kernel at the clock an idle datapath gets: what the schedule alone achieves (tools/power_probe.py)

@@ -73,6 +73,17 @@ static __device__ __forceinline__ void lds_dma16_si(const void *sbase, unsigned 
                  : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
                  : "memory", "m0", "scc");
 }
+// ... and an immediate byte offset (-4096 .. 4095): several transfers off ONE scalar base.  The hardware adds the instruction's offset to the LDS address
+// as well (LDS address = m0 + offset + lane * 16 -- measured: with m0 = the destination every piece landed GOFF bytes off), so m0 = destination - GOFF
+template <unsigned LDS_IMM, int GOFF>
+static __device__ __forceinline__ void lds_dma16_sio(const void *sbase, unsigned voff, unsigned lds_base)
+{
+    static_assert(GOFF >= -4096 && GOFF <= 4095, "global_load_lds immediate offset");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_base), "n"((int)LDS_IMM - GOFF), "n"(GOFF)
+                 : "memory", "m0", "scc");
+}
 // 16-byte store at (scalar base + 32-bit per-lane byte offset): ONE address register however many stores share the lane offset
 static __device__ __forceinline__ void store16_s(const void *sbase, unsigned voff, f32x4 v)
 {

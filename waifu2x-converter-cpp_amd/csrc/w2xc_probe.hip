@@ -1,7 +1,7 @@
 // libw2xc_probe.so -- MEASUREMENT AID for bench.py, not part of the drop-in (include/w2xc_hip.h does not declare it, libw2xc_hip.so does not contain it).
 // gpurun boxes differ (the same conv3x3_wino4<128,128> launch: 6.5 ms on most, 8.7 ms on one -- profiles/r5_sweeps.log block 8); the roofline fraction
 // is priced at the nominal 2.4 GHz, so bench.py records beside it what the matrix pipes of THIS box deliver: every SIMD of the chip runs a stream of
-// independent v_mfma_f32_16x16x4_f32 (8 passes = 32 cycles each, two waves per SIMD so that the loop overhead hides), and
+// independent v_mfma_f32_16x16x4_f32 on random operands (8 passes = 32 cycles each, two waves per SIMD so that the loop overhead hides), and
 //     MHz = MFMAs per SIMD per second x 32 / 1e6.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(512, 1) probe_mfma(const float *in, float *out
     }
     f32x4 s = acc[0];
     for (int i = 1; i < 16; i++) s += acc[i];
-    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[threadIdx.x] = s[0];   // (keeps the chain alive; never true for the zero operands below)
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[threadIdx.x] = s[0];   // (keeps the chain alive)
 }
 
 // Runs the stream for about `ms` milliseconds on `device` and returns the matrix pipes' MHz-equivalent (< 0: a HIP error, printed to stderr).
@@ -31,7 +31,10 @@ extern "C" double w2xc_probe_mfma_mhz(int device, int ms)
     const int cus = prop.multiProcessorCount;
     float *buf = nullptr;
     CK(hipMalloc(&buf, 4096));
-    CK(hipMemset(buf, 0, 4096));
+    float h[1024];                                        // operands in (-1, 1): a datapath that toggles is what the clock is granted for (zeros run faster)
+    unsigned r = 12345u;
+    for (int i = 0; i < 1024; i++) { r = r * 1664525u + 1013904223u; h[i] = (float)(int)(r >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+    CK(hipMemcpy(buf, h, sizeof h, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));

@@ -227,6 +227,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         const char *sbase = wpk_w + ((size_t)(ob * NST + s_) * 36 + q * DW) * 1024;
         lds_dma16_si<U_BASE + slot * U_BYTES + q * DW * 1024u>(sbase, b_voff, wbase);
     };
+#ifndef W4_DMA_BASES
+#define W4_DMA_BASES 1   // 1: a stage's U pieces go off scalar bases formed ONCE per stage / per pair of pieces (immediate offsets -4096 | 0), 0: every piece forms its own
+#endif
+    // (one instantiation -- 32 planar planes in, 128 NHWC planes out, not on the default path -- spills four registers with the two more live scalars: it keeps the old form)
+    constexpr bool DMAB = W4_DMA_BASES && W4_DMA4 && !(CIN == 32 && COUT == 128 && !OUT_PLANAR && !IN_NHWC && !FUSE7);
+    // the same off a base the caller keeps: u_pair = (this wave's piece q | 1 of the stage), pieces q even at -4096, q odd at 0
+    auto dma_u_pair = [&](const char *u_pair, auto SLOT, auto Q) {
+        constexpr unsigned slot = decltype(SLOT)::value;
+        constexpr int q = decltype(Q)::value;
+        lds_dma16_sio<U_BASE + slot * U_BYTES + q * DW * 1024u, (q & 1) ? 0 : -(DW * 1024)>(u_pair, b_voff, wbase);
+    };
 
     // ---- addressing ----
     // MFMA operands: lane-linear 16-byte quads, (wave-uniform base) + lane * 16: A = U at U_BASE + slot * U_BYTES + pt * 1024 + (xi / 4) * 4096,
@@ -432,6 +443,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             if (s == NST - 1) { u_ob = item_n % NOB; u_s = 0; }
             const char *ua = ua_of(par);
             const char *va = va_of(par);
+            // this wave's first U piece of the stage it transfers, formed once (left to the compiler every piece recomputed it from (u_ob, u_s): ~6 scalar
+            // instructions per piece in front of an MFMA that waits for them in program order)
+            const char *u_st = wpk_w + (size_t)(u_ob * NST + u_s) * 36864, *u_pair = u_st;
+            if constexpr (DMAB) asm volatile("" : "+s"(u_st));
             const char *srcQ = nullptr;
             char *dstQ = nullptr;
             if constexpr (QT == 0) srcQ = ldsb + (rd + tr_rd());
@@ -486,11 +501,22 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 constexpr int TSTEP = W4_DMA4 ? 1 : 2, tk = xi >= 1 && (xi - 1) % TSTEP == 0 ? (xi - 1) / TSTEP : -1;   // transfer slot behind MFMA xi
                 if constexpr (tk >= 0 && tk < UQ && !(W4_ABL & 16)) {
                     constexpr int q = tk;
-                    if (wave < (q == UQ - 1 ? 36 - (UQ - 1) * DW : DW)) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, q>{});
+                    if constexpr (DMAB) {
+                        if (wave < (q == UQ - 1 ? 36 - (UQ - 1) * DW : DW)) {
+                            if constexpr ((q & 1) == 0) {   // the base of pieces q and q + 1: one 64-bit scalar addition per pair
+                                u_pair = u_st + (q + 1) * (DW * 1024);
+                                asm volatile("" : "+s"(u_pair));
+                            }
+                            dma_u_pair(u_pair, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, q>{});
+                        }
+                    } else {
+                        if (wave < (q == UQ - 1 ? 36 - (UQ - 1) * DW : DW)) dma_u(u_ob, u_s, std::integral_constant<unsigned, nxt>{}, std::integral_constant<int, q>{});
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (tk >= UQ && tk < UQ + RJ && !(W4_ABL & 32)) {
                     constexpr int jj = tk - UQ;      // slice s + 6 into the buffer Q0 of stage s - 1 has read
+                    // (the slice base of these two or three pieces formed once per stage as well: two more live scalars, 4 VGPR spills in the planar kernel, slower)
                     if (wave < (jj == RJ - 1 ? RAW_PIECES - (RJ - 1) * DW : DW)) dma_raw(std::integral_constant<int, jj>{}, fr, r_slice);
                     __builtin_amdgcn_sched_barrier(0);
                 }
