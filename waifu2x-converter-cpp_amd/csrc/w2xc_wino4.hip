@@ -685,6 +685,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
     };
+#ifdef W4_ONE_PH   // timing-only (tools/ubench): every wave runs the copy of phase W4_ONE_PH -- wrong results, the same work per stage, a quarter of the hot code
+    run(std::integral_constant<int, W4_ONE_PH>{});
+    return;
+#endif
     switch ((pt - 2 * bt) & 3) {
     case 0: run(std::integral_constant<int, 0>{}); break;
     case 1: run(std::integral_constant<int, 1>{}); break;
