@@ -654,7 +654,7 @@ def main():
         out.update(extras)
         mhz = probe_matrix_clock(w2xc.LIB_PATH, dev_index)
         if mhz:
-            # gpurun boxes differ by up to 30 % on the same launch: what THIS box's matrix pipes deliver under an all-SIMD MFMA stream, beside the
+            # gpurun boxes differ by a few percent on the same launch: what THIS box's matrix pipes deliver under an all-SIMD MFMA stream, beside the
             # nominal clock `roofline.peak` is priced at (the fraction itself stays at the nominal peak)
             out["matrix_clock"] = {"mfma_equiv_mhz": mhz, "nominal_mhz": 2400.0, "ratio": round(mhz / 2400.0, 4),
                                    "how": "libw2xc_probe.so: 30 ms of independent v_mfma_f32_16x16x4_f32 on random operands on every SIMD, MFMAs/s/SIMD x 32 cycles, after the timed passes"}

@@ -1,5 +1,5 @@
 // libw2xc_probe.so -- MEASUREMENT AID for bench.py, not part of the drop-in (include/w2xc_hip.h does not declare it, libw2xc_hip.so does not contain it).
-// gpurun boxes differ (the same conv3x3_wino4<128,128> launch: 6.5 ms on most, 8.7 ms on one -- profiles/r5_sweeps.log block 8); the roofline fraction
+// gpurun boxes differ by a few percent (bench.py's frame: 13.75-14.29 ms over five boxes of one afternoon, profiles/r5_sweeps.log); the roofline fraction
 // is priced at the nominal 2.4 GHz, so bench.py records beside it what the matrix pipes of THIS box deliver: every SIMD of the chip runs a stream of
 // independent v_mfma_f32_16x16x4_f32 on random operands (8 passes = 32 cycles each, two waves per SIMD so that the loop overhead hides), and
 //     MHz = MFMAs per SIMD per second x 32 / 1e6.
