@@ -467,7 +467,7 @@ def convertWithModels(inputPlane, outputPlane, models, blockSplitting=True, opts
 # ---- sharding one plane into independent row bands (multi-GPU: no exchange, host-side gather) ----
 def shard_rows(plane_h, n_parts, part):
     """Output rows [begin, end) of shard `part` of `n_parts` (contiguous, sizes differ by <= 1 row).
-    Same split as the in-process multi-device path of w2xc_convert_plane (csrc/w2xc_engine.cpp)."""
+    Same split as the in-process multi-device path of w2xc_convert_plane (csrc/w2xc_host_pipeline.cpp)."""
     return (plane_h * part) // n_parts, (plane_h * (part + 1)) // n_parts
 
 

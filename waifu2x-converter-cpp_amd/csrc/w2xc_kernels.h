@@ -1,4 +1,4 @@
-// w2xc_kernels.h -- launch interface between the engine (w2xc_engine.cpp) and the gfx950
+// w2xc_kernels.h -- launch interface between the engine (w2xc_rows.cpp, see w2xc_engine.hpp) and the gfx950
 // kernels (w2xc_kernels.hip).  One "layer launch" computes
 //     out(y,x,o) = leaky( bias[o] + sum_{i,r,c} W[o][i][r][c] * in(clamp(y+r+off_y), clamp(x+c+off_x), i) )
 // which is Model::filterWorker (/root/reference/src/modelHandler.cpp:117-159) on one haloed
