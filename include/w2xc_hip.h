@@ -77,7 +77,7 @@ typedef struct w2xc_model w2xc_model;
 
 typedef struct w2xc_opts {
     int      struct_size;     /* sizeof(w2xc_opts): ABI versioning                                   */
-    int      precision;       /* W2XC_PRECISION_*  (opts == NULL: the env var W2XC_PRECISION, default fp32)  */
+    int      precision;       /* W2XC_PRECISION_*  (opts == NULL: the process defaults, w2xc_set_default_opts)  */
     int      kernel;          /* W2XC_KERNEL_*                                                       */
     int      device;          /* device-pointer entry points: HIP device ordinal, -1 = current      */
     unsigned device_mask;     /* host-pointer entry points: bit i = use device i; 0 = all devices   */
@@ -88,26 +88,42 @@ typedef struct w2xc_opts {
     int      filter_resident; /* w2xc_layer_filter: 1 = when the input planes are exactly the planes the previous
                                * w2xc_layer_filter call on this model wrote (same pointers, count, size) the caller
                                * promises they are unmodified, and the copy still on the device is used instead of
-                               * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: env
-                               * W2XC_FILTER_RESIDENT=1.  Default 0: every call uploads what it is given.          */
+                               * uploading them again (chained Model::filter, test.cpp:72-85).  opts == NULL: the
+                               * process defaults (w2xc_set_default_opts).  Default 0: every call uploads what it is given. */
     int      fusion;          /* W2XC_FUSION_*: cross-layer fusion on the fp32 path -- convertRoutine.cpp:66-76's loop collapsed by two launches:
                                * (a) the one-plane last layer inside the epilogue of the layer before it (the default kernel conv3x3_wino4
                                *     carries it; conv3x3_last_gather finishes), (b) layers 1 (1 -> 32) and 2 (32 -> 32) in one launch,
                                *     conv3x3_first2_wino4: layer 1's activations never reach HBM.  W2XC_FUSION_AUTO = both on where the
-                               *     model's shapes allow, W2XC_FUSION_OFF runs every layer as its own launch.  Results stay inside the
+                               *     model's shapes allow (a fusion whose kernel cannot address the plane is given up, never an error),
+                               *     W2XC_FUSION_OFF runs every layer as its own launch, W2XC_FUSION_FIRST / _LAST allow only (b) / only (a),
+                               *     W2XC_FUSION_ON = both, and W2XC_ERR_UNSUPPORTED where AUTO would give one up.  Results stay inside the
                                *     fp32 gate either way (fused vs unfused <= 4e-6 of the output range, tests/test_gpu_winograd.py).
-                               * (The 16-bit modes: environment W2XC_SPLIT_FUSE_FIRST / _LAST.) */
+                               * The 16-bit modes have the same two fusions (conv3x3_first2_split, conv3x3_split + gather) under the same switch. */
     int      host_units;      /* host-pointer entry points, test aid: cut the rows into this many units, round-robin over the selected
                                * devices, so a one-GPU box runs the multi-device arithmetic; 0 = one unit per device              */
     int      host_chunk_kb;   /* host-pointer entry points, test aid: maximum size of a staged output chunk in KiB; 0 = 8192     */
+    int      host_numa;       /* host-pointer entry points: 0 = a unit's feeder / drainer threads and pinned rings are placed on the CPU
+                               * node its device hangs off (multi-socket hosts), 1 = the caller's affinity is left alone            */
 } w2xc_opts;                  /* (verbose: bit 0 = the reference's progress lines, bit 1 = the host pipeline's phase timestamps on stderr) */
 
-#define W2XC_FUSION_AUTO 0
-#define W2XC_FUSION_OFF  1
-#define W2XC_FUSION_ON   2
+#define W2XC_FUSION_AUTO  0
+#define W2XC_FUSION_OFF   1
+#define W2XC_FUSION_ON    2
+#define W2XC_FUSION_FIRST 3   /* only layers 1 + 2 in one launch */
+#define W2XC_FUSION_LAST  4   /* only the last layer inside the epilogue of the layer before it */
 
-/* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding). */
+/* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding).  Writes sizeof(w2xc_opts) bytes of THIS header's
+ * struct: a binary compiled against an older, shorter w2xc_opts must call w2xc_opts_init_sized with ITS sizeof (or be rebuilt) --
+ * the ABI version string (w2xc_version) changes whenever the struct grows. */
 void w2xc_opts_init(w2xc_opts *o);
+/* The same for a caller that knows only the first `struct_size` bytes of w2xc_opts (an older header): nothing past them is written, and
+ * o->struct_size is set to it, which is what every entry point honours when it reads the options back. */
+void w2xc_opts_init_sized(w2xc_opts *o, size_t struct_size);
+/* What `opts == NULL` means for this process (the C++ adapter behind the reference's unmodified callers passes no options).  Initially:
+ * w2xc_opts_init's defaults with precision from the environment variable W2XC_PRECISION (fp32 | fp16x2 | bf16x3 | bf16x2 | bf16) and
+ * filter_resident from W2XC_FILTER_RESIDENT (0 | 1) -- the only two environment variables the library reads, once, here.  Passing a
+ * struct replaces the defaults; passing NULL re-reads the environment.  Thread-safe; calls already running keep what they resolved. */
+int w2xc_set_default_opts(const w2xc_opts *defaults);
 
 /* ---- model container (modelHandler.hpp:24-90, modelHandler.cpp:74-115,170-197) ------------- */
 
@@ -281,6 +297,25 @@ int  w2xc_profile_read(w2xc_model *m, int device, float *layer_ms, int *layer_la
 void w2xc_profile_reset(w2xc_model *m, int device);
 /* name of the kernel the engine picks for a layer (for matching rocprofv3 kernel traces) */
 const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_opts *opts);
+
+/* The band geometry a w2xc_convert_rows_device call with these arguments would run with, computed on the host (no device needed, nothing is
+ * allocated or launched): halo rows per layer (1, or 4 = the banding-invariant geometry of the default F(4x4) kernel), output rows per band,
+ * number of bands, bytes of the two activation workspaces, and whether the two cross-layer fusions are in effect.  Fails exactly where the
+ * conversion would refuse its arguments (W2XC_ERR_ARG for W2XC_KERNEL_AUTO on a minimum-halo view, W2XC_ERR_PLANES ...). */
+typedef struct w2xc_row_plan {
+    int struct_size;
+    int n_layers;
+    int halo_rows_per_layer;
+    int band_rows;
+    int n_bands;
+    int fused_first, fused_last;
+    unsigned long long workspace_bytes[2];
+} w2xc_row_plan;
+int w2xc_plan_rows(const w2xc_model *m, int w, int view_y0, int view_h, int plane_h, int row_begin, int row_end, const w2xc_opts *opts,
+                   w2xc_row_plan *plan);
+/* plane rows [*top, *bottom) that layer `layer` (1 .. n_layers) computes for the band of output rows [y0, y1) under `plan`
+ * (negative rows / rows >= plane_h + ...: the replicate padding of convertRoutine.cpp:35 seen from that layer) */
+int w2xc_plan_region(const w2xc_row_plan *plan, int plane_h, int layer, int y0, int y1, int *top, int *bottom);
 
 int w2xc_device_count(void);          /* hipGetDeviceCount, 0 when no device / no driver           */
 const char *w2xc_last_error(void);    /* thread-local message of the last failing call             */

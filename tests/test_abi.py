@@ -167,7 +167,7 @@ def test_opts_struct_size_versions_the_abi(w2xc, noise1_layers):
     new.future_a = -1
     assert name(ms.handle, 0, C.cast(C.byref(new), C.POINTER(w2xc.Opts))) == b"conv3x3_direct"
     o = w2xc.make_opts()
-    assert o.filter_resident == 0 and o.fusion == w2xc.FUSION_AUTO and o.struct_size == C.sizeof(w2xc.Opts) == 52 and o.host_units == 0 and o.host_chunk_kb == 0
+    assert o.filter_resident == 0 and o.fusion == w2xc.FUSION_AUTO and o.struct_size == C.sizeof(w2xc.Opts) == 56 and o.host_units == 0 and o.host_chunk_kb == 0 and o.host_numa == 0
 
 
 def test_hostile_model_files_do_not_cross_the_abi(w2xc, tmp_path):

@@ -680,23 +680,29 @@ def test_host_multi_band_path(gpu, scale_layers):
     assert np.array_equal(ms.convert_nn2x(x), ms.convert_nn2x(x, opts=o3))
 
 
-def test_default_precision_from_environment(gpu, scale_layers, tmp_path):
-    """callers that pass no w2xc_opts (the C++ adapter behind the unmodified CLI) get W2XC_PRECISION from the
-    environment: the bf16x3 run must equal an explicit BF16X3 call bit for bit, and differ from fp32."""
-    import subprocess, sys
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from tools import gen_model\n"
-        "w = g.load_package(); ms = w._ModelSet.from_layers(gen_model.synth_layers(seed=102))\n"
-        "x = np.random.default_rng(4).random((64, 96), dtype=np.float32)\n"
-        "np.save(sys.argv[1], np.stack([ms.convert(x), ms.convert(x, opts=w.make_opts(precision=w.PRECISION_BF16X3)),\n"
-        "                               ms.convert(x, opts=w.make_opts(precision=w.PRECISION_FP32))]))\n" % ROOT)
-    f = str(tmp_path / "o.npy")
-    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_PRECISION="bf16x3"), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    default, x3, fp32 = np.load(f)
-    assert np.array_equal(default, x3) and not np.array_equal(default, fp32)
+def test_default_precision_from_environment(gpu, scale_layers, monkeypatch):
+    """callers that pass no w2xc_opts (the C++ adapter behind the unmodified CLI) get the process defaults: W2XC_PRECISION from the
+    environment (read where the defaults are formed -- w2xc_set_default_opts(NULL) re-reads it), or whatever w2xc_set_default_opts was given.
+    The bf16x3 default must equal an explicit BF16X3 call bit for bit, and differ from fp32."""
+    ms = gpu._ModelSet.from_layers(scale_layers)
+    x = np.random.default_rng(4).random((64, 96), dtype=np.float32)
+    x3 = ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_BF16X3))
+    fp32 = ms.convert(x, opts=gpu.make_opts(precision=gpu.PRECISION_FP32))
+    assert not np.array_equal(x3, fp32)
+    try:
+        monkeypatch.setenv("W2XC_PRECISION", "bf16x3")
+        assert gpu.lib().w2xc_set_default_opts(None) == 0
+        assert np.array_equal(ms.convert(x), x3)
+        monkeypatch.delenv("W2XC_PRECISION")
+        assert gpu.lib().w2xc_set_default_opts(None) == 0
+        assert np.array_equal(ms.convert(x), fp32)
+        o = gpu.make_opts(precision=gpu.PRECISION_BF16X3)
+        assert gpu.lib().w2xc_set_default_opts(o) == 0
+        assert np.array_equal(ms.convert(x), x3)
+    finally:
+        monkeypatch.delenv("W2XC_PRECISION", raising=False)
+        gpu.lib().w2xc_set_default_opts(None)
+    assert np.array_equal(ms.convert(x), fp32)
 
 
 def test_cli_shell_precision_flag(gpu, models_dir, tmp_path):
@@ -717,67 +723,50 @@ def test_cli_shell_precision_flag(gpu, models_dir, tmp_path):
     assert outs[0].shape == (48, 56, 3) and np.abs(outs[0] - outs[1]).max() <= 1
 
 
-def test_fused_last_layer_vs_unfused(gpu, tmp_path):
+def test_fused_last_layer_vs_unfused(gpu):
     """the 16-bit modes compute the one-plane last layer inside the epilogue of the layer before it (conv3x3_split
-    out_terms = 9 + conv3x3_last_gather).  W2XC_SPLIT_FUSE_LAST=0 restores the separate fp32 conv3x3_last: the two
+    out_terms = 9 + conv3x3_last_gather).  w2xc_opts.fusion = W2XC_FUSION_FIRST restores the separate fp32 conv3x3_last: the two
     must agree to the fp32-order level on odd sizes, borders, banding and the nearest-2x entry point."""
-    import subprocess, sys
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from tools import gen_model\n"
-        "w = g.load_package(); outs = []; flags = []\n"
-        "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 1], 7), ([1, 64, 32, 1], 8)):\n"
-        "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
-        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2, w.PRECISION_BF16X3):\n"
-        "        for (h, wd) in ((37, 61), (8, 32), (130, 70)):\n"
-        "            x = np.random.default_rng(h).random((h, wd), dtype=np.float32)\n"
-        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec)).ravel())\n"
-        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec, band_rows=11)).ravel())\n"
-        "            outs.append(ms.convert_nn2x(x, w.make_opts(precision=prec)).ravel())\n"
-        "    flags.append(float(ms.kernel_name(len(planes) - 2, w.make_opts(precision=w.PRECISION_FP16X2)) == 'conv3x3_last_gather'))\n"
-        "np.save(sys.argv[1], np.concatenate(outs + [np.array(flags)]))\n" % ROOT)
     res = []
-    for fuse in ("1", "0"):
-        f = str(tmp_path / ("o%s.npy" % fuse))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_SPLIT_FUSE_LAST=fuse), capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        res.append(np.load(f))
-    a, b = res
+    for fusion in (gpu.FUSION_AUTO, gpu.FUSION_FIRST):
+        outs, flags = [], []
+        for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 1], 7), ([1, 64, 32, 1], 8)):
+            ms = gpu._ModelSet.from_layers(gen_model.synth_layers(planes, seed))
+            for prec in (gpu.PRECISION_FP16X2, gpu.PRECISION_BF16X2, gpu.PRECISION_BF16X3):
+                for (h, wd) in ((37, 61), (8, 32), (130, 70)):
+                    x = np.random.default_rng(h).random((h, wd), dtype=np.float32)
+                    outs.append(ms.convert(x, opts=gpu.make_opts(precision=prec, fusion=fusion)).ravel())
+                    outs.append(ms.convert(x, opts=gpu.make_opts(precision=prec, fusion=fusion, band_rows=11)).ravel())
+                    outs.append(ms.convert_nn2x(x, gpu.make_opts(precision=prec, fusion=fusion)).ravel())
+            flags.append(ms.kernel_name(len(planes) - 2, gpu.make_opts(precision=gpu.PRECISION_FP16X2, fusion=fusion)) == 'conv3x3_last_gather')
+        res.append((np.concatenate(outs), flags))
+    (a, fa), (b, fb) = res
     assert a.shape == b.shape
-    assert (a[-3:] == 1.0).all() and (b[-3:] == 0.0).all()          # the fused path really ran (and really did not)
-    scale = np.abs(b[:-3]).max()
-    assert np.abs(a[:-3] - b[:-3]).max() <= 1e-4 * scale            # BF16X2 bound; FP16X2 is ~1e-6
+    assert all(fa) and not any(fb)                                  # the fused path really ran (and really did not)
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() <= 1e-4 * scale                      # BF16X2 bound; FP16X2 is ~1e-6
 
 
-def test_fused_first_two_layers_vs_unfused(gpu, tmp_path):
+def test_fused_first_two_layers_vs_unfused(gpu):
     """the 16-bit modes run layers 1 (1 -> 32) and 2 (32 -> C) as ONE kernel (conv3x3_first2_split: layer 1's terms stay in
     LDS).  It uses the same arithmetic in the same order as conv3x3_first_split + conv3x3_split, so with
-    W2XC_SPLIT_FUSE_FIRST=0 the results must be BIT-IDENTICAL -- odd sizes, borders, banding, nearest-2x, every precision."""
-    import subprocess, sys
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as g; from tools import gen_model\n"
-        "w = g.load_package(); outs = []; flags = []\n"
-        "for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 32, 1], 7), ([1, 32, 128, 64, 1], 8), ([1, 32, 32, 3], 9)):\n"
-        "    ms = w._ModelSet.from_layers(gen_model.synth_layers(planes, seed))\n"
-        "    for prec in (w.PRECISION_FP16X2, w.PRECISION_BF16X2, w.PRECISION_BF16X3, w.PRECISION_BF16):\n"
-        "        if planes[-1] != 1: continue\n"
-        "        for (h, wd) in ((37, 61), (8, 32), (130, 70)):\n"
-        "            x = np.random.default_rng(h).random((h, wd), dtype=np.float32)\n"
-        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec)).ravel())\n"
-        "            outs.append(ms.convert(x, opts=w.make_opts(precision=prec, band_rows=11)).ravel())\n"
-        "            outs.append(ms.convert_nn2x(x, w.make_opts(precision=prec)).ravel())\n"
-        "    flags.append(float(ms.kernel_name(1, w.make_opts(precision=w.PRECISION_FP16X2)) == 'conv3x3_first2_split'))\n"
-        "np.save(sys.argv[1], np.concatenate(outs + [np.array(flags)]))\n" % ROOT)
+    w2xc_opts.fusion = W2XC_FUSION_LAST the results must be BIT-IDENTICAL -- odd sizes, borders, banding, nearest-2x, every precision."""
     res = []
-    for fuse in ("1", "0"):
-        f = str(tmp_path / ("o%s.npy" % fuse))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, W2XC_SPLIT_FUSE_FIRST=fuse), capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        res.append(np.load(f))
-    a, b = res
+    for fusion in (gpu.FUSION_AUTO, gpu.FUSION_LAST):
+        outs, flags = [], []
+        for planes, seed in (([1, 32, 32, 64, 64, 128, 128, 1], 102), ([1, 32, 64, 32, 1], 7), ([1, 32, 128, 64, 1], 8), ([1, 32, 32, 3], 9)):
+            ms = gpu._ModelSet.from_layers(gen_model.synth_layers(planes, seed))
+            for prec in (gpu.PRECISION_FP16X2, gpu.PRECISION_BF16X2, gpu.PRECISION_BF16X3, gpu.PRECISION_BF16):
+                if planes[-1] != 1:
+                    continue
+                for (h, wd) in ((37, 61), (8, 32), (130, 70)):
+                    x = np.random.default_rng(h).random((h, wd), dtype=np.float32)
+                    outs.append(ms.convert(x, opts=gpu.make_opts(precision=prec, fusion=fusion)).ravel())
+                    outs.append(ms.convert(x, opts=gpu.make_opts(precision=prec, fusion=fusion, band_rows=11)).ravel())
+                    outs.append(ms.convert_nn2x(x, gpu.make_opts(precision=prec, fusion=fusion)).ravel())
+            flags.append(ms.kernel_name(1, gpu.make_opts(precision=gpu.PRECISION_FP16X2, fusion=fusion)) == 'conv3x3_first2_split')
+        res.append((np.concatenate(outs), flags))
+    (a, fa), (b, fb) = res
     assert a.shape == b.shape
-    assert (a[-4:] == 1.0).all() and (b[-4:] == 0.0).all()          # the fused kernel really ran (and really did not)
-    assert np.array_equal(a[:-4], b[:-4])
+    assert all(fa) and not any(fb)                                  # the fused kernel really ran (and really did not)
+    assert np.array_equal(a, b)

@@ -61,6 +61,27 @@ def test_host_pipeline_bit_identical_to_resident_path(gpu, scale_layers, monkeyp
         assert np.array_equal(ms.convert(y, opts=ho), device_result(gpu, ms, y))
 
 
+@pytest.mark.parametrize("planes", [[1, 32, 32, 64, 32, 1], [1, 32, 32, 64, 64, 1], [1, 32, 32, 64, 64, 128, 128, 1]])
+def test_chunked_first_launch_waits_for_the_whole_block_it_touches(gpu, planes):
+    """the fused first launch (layers 1 + 2) runs in row chunks under the upload of the source plane.  A chunk ends on a multiple of 8 local rows,
+    which is a 4x4-block edge only when the region starts on one ((n - 2) & 3 == 0 ...): the block straddling the end reads source rows
+    beyond the chunk's last row + 4, and the launch must wait for THEM -- otherwise its stored rows depend on what the device copy of the
+    source held before (here: NaN from the previous call, which no cancellation removes).  host == resident bit for bit, small chunks."""
+    ms = gpu._ModelSet.from_layers(small_layers(planes, 31 + len(planes)))
+    assert ms.kernel_name(1) == "conv3x3_first2_wino4"
+    poison = np.full((301, 423), np.nan, np.float32)
+    for it in range(4):
+        x = rand_plane(301, 423, 50 + it)
+        want = device_result(gpu, ms, x)
+        assert np.isfinite(want).all()
+        for kb in (16, 48):
+            ms.convert(poison, opts=gpu.make_opts(host_chunk_kb=kb))            # the pipe's device rows now hold NaN everywhere
+            got = ms.convert(x, opts=gpu.make_opts(host_chunk_kb=kb))
+            assert np.array_equal(got, want), (planes, it, kb, int(np.isnan(got).sum()))
+            got = ms.convert_nn2x(x[:150, :211], opts=gpu.make_opts(host_chunk_kb=kb))
+            assert np.array_equal(got, device_result(gpu, ms, x[:150, :211], True))
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16x2", "bf16", "direct"])
 def test_host_pipeline_multi_band_and_every_last_layer_kernel(gpu, scale_layers, monkeypatch, precision):
     """several workspace bands (upload of band k+1 under band k) x chunked last layer, for every kernel the last layer can be:

@@ -30,7 +30,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libw2xc_hip.so")
 OK, ERR_IO, ERR_JSON, ERR_ARG, ERR_PLANES, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 PRECISION_FP32, PRECISION_BF16, PRECISION_BF16X2, PRECISION_BF16X3, PRECISION_FP16X2 = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MFMA, KERNEL_WINOGRAD, KERNEL_WINOGRAD32, KERNEL_WINOGRAD4 = 0, 1, 2, 3, 4, 5
-FUSION_AUTO, FUSION_OFF, FUSION_ON = 0, 1, 2
+FUSION_AUTO, FUSION_OFF, FUSION_ON, FUSION_FIRST, FUSION_LAST = 0, 1, 2, 3, 4
 
 
 class W2xcError(RuntimeError):
@@ -44,7 +44,13 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("precision", C.c_int), ("kernel", C.c_int), ("device", C.c_int),
                 ("device_mask", C.c_uint), ("band_rows", C.c_int), ("workspace_mb", C.c_int),
                 ("profile", C.c_int), ("verbose", C.c_int), ("filter_resident", C.c_int), ("fusion", C.c_int),
-                ("host_units", C.c_int), ("host_chunk_kb", C.c_int)]
+                ("host_units", C.c_int), ("host_chunk_kb", C.c_int), ("host_numa", C.c_int)]
+
+
+class RowPlan(C.Structure):
+    """struct w2xc_row_plan (include/w2xc_hip.h): the band geometry of one row-range conversion."""
+    _fields_ = [("struct_size", C.c_int), ("n_layers", C.c_int), ("halo_rows_per_layer", C.c_int), ("band_rows", C.c_int),
+                ("n_bands", C.c_int), ("fused_first", C.c_int), ("fused_last", C.c_int), ("workspace_bytes", C.c_ulonglong * 2)]
 
 
 def _load():
@@ -63,6 +69,10 @@ def _load():
     vp, ci, cs, fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
     sig = {
         "w2xc_opts_init": (None, [C.POINTER(Opts)]),
+        "w2xc_opts_init_sized": (None, [C.POINTER(Opts), cs]),
+        "w2xc_set_default_opts": (ci, [C.POINTER(Opts)]),
+        "w2xc_plan_rows": (ci, [vp, ci, ci, ci, ci, ci, ci, C.POINTER(Opts), C.POINTER(RowPlan)]),
+        "w2xc_plan_region": (ci, [C.POINTER(RowPlan), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),
         "w2xc_model_load_json": (ci, [C.c_char_p, C.POINTER(vp)]),
         "w2xc_model_from_arrays": (ci, [ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "w2xc_model_free": (None, [vp]),
@@ -349,6 +359,27 @@ class _ModelSet:
         if rc != OK:
             raise W2xcError(rc, last_error())
         return out
+
+    def plan_rows(self, w, plane_h, row_begin=0, row_end=None, view_y0=0, view_h=None, opts=None):
+        """The band geometry a row-range conversion would run with (w2xc_plan_rows): no device needed."""
+        row_end = plane_h if row_end is None else row_end
+        view_h = plane_h - view_y0 if view_h is None else view_h
+        p = RowPlan()
+        p.struct_size = C.sizeof(RowPlan)
+        rc = _lib.w2xc_plan_rows(self.handle, w, view_y0, view_h, plane_h, row_begin, row_end,
+                                 C.byref(opts) if opts is not None else None, C.byref(p))
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+        return p
+
+    @staticmethod
+    def plan_region(plan, plane_h, layer, y0, y1):
+        """plane rows [top, bottom) layer `layer` (1-based) computes for the band [y0, y1) under `plan` (w2xc_plan_region)"""
+        t, b = C.c_int(), C.c_int()
+        rc = _lib.w2xc_plan_region(C.byref(plan), plane_h, layer, y0, y1, C.byref(t), C.byref(b))
+        if rc != OK:
+            raise W2xcError(rc, last_error())
+        return t.value, b.value
 
     def kernel_name(self, layer, opts=None):
         return _lib.w2xc_layer_kernel_name(self.handle, layer, C.byref(opts) if opts is not None else None).decode()

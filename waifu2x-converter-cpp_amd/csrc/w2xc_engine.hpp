@@ -233,6 +233,21 @@ int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o);
 int fused_halves(int T, int cout);
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO4 = 3 };
 
+// the band geometry of one run_rows call (plan_rows, w2xc_select.cpp): pure host arithmetic
+struct RowPlan {
+    w2xc_opts o;              // the options the call runs with (W2XC_FUSION_AUTO gives up a fusion whose kernel cannot address the plane)
+    int n = 0, w = 0, plane_h = 0;
+    int HL = 1;               // halo rows per layer: 1, or 4 = the banding-invariant geometry of conv3x3_wino4
+    int T = 0;                // 16-bit terms per activation (0 = fp32)
+    int band = 0;             // output rows per band
+    bool last_direct = false, all_out = false;
+    W2xcKernelKind last_kind = W2XC_K_DIRECT;
+    size_t need[2] = {0, 0};  // bytes of the two ping-pong workspaces for one band
+    void region(int k, int y0, int y1, int &T_, int &B_) const;
+    void ws_need(const w2xc_model *m, int rows, size_t need_[2]) const;
+};
+int plan_rows(const w2xc_model *m, const w2xc_opts &o_in, int w, int vh, int vy0, int ra, int rb, int plane_h, int n_in, bool all_out, RowPlan *p);
+
 // ---- w2xc_rows.cpp ----
 int launch_layer(DevCtx *c, const w2xc_model *m, int l, W2xcKernelKind kind, W2xcConvDesc d, hipStream_t st, const w2xc_opts &o);
 

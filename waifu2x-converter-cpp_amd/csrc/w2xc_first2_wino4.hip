@@ -304,7 +304,8 @@ hipError_t w2xc_launch_first2_wino4(const W2xcConvDesc &d, hipStream_t stream)
     if (d.out_w <= 0 || d.out_h <= 0) return hipSuccess;
     if (d.cin != 32 || d.cout != 32 || !d.w1pk || !d.bias1 || d.in_ps != 1 || d.in_shift < 0 || d.in_shift > 1 || d.out_terms != 0) return hipErrorInvalidValue;
     if (d.out_ps != 1 || (d.out_rs & 3) != 0 || (d.out_cs & 3) != 0 || (((size_t)d.out) & 15) != 0 || d.out_rs < ((d.out_w + 3) & ~3)) return hipErrorInvalidValue;
-    if (13ll * d.out_cs * 4 + 64ll * d.out_rs >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit lane offsets: 12 planes + the rows of one
+    // 32-bit lane offsets: 12 plane strides + a row of THIS launch's region + a pixel -- the largest one a lane forms, whatever the relation of the strides
+    if (12ll * d.out_cs * 4 + ((long long)d.out_h + 8) * d.out_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 3) + 7) / 8;
     const int ntiles = tiles_x * tiles_y;
     constexpr size_t lds_bytes = 36 * 2 * 64 * 16 + 12 * 40 * 4 + 32 * 12 * 4;   // V (then M over it): 72 KiB; the source tile; layer 1's weights

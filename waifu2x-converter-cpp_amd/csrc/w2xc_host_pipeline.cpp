@@ -64,11 +64,9 @@ int pipe_init(HostPipe &p)
 }
 
 // ---- NUMA placement of a device's host pipeline (multi-socket hosts: the pinned rings and the threads that fill / drain them belong
-// on the CPU node the GPU hangs off, or every staged byte crosses the inter-socket link twice).  W2XC_NUMA=0 disables. ----
+// on the CPU node the GPU hangs off, or every staged byte crosses the inter-socket link twice).  w2xc_opts.host_numa = 1 disables. ----
 int numa_node_of_device(int dev)
 {
-    static const bool enabled = [] { const char *e = getenv("W2XC_NUMA"); return !(e && atoi(e) == 0); }();
-    if (!enabled) return -1;
     int node = -1;
     if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, dev) == hipSuccess && node >= 0) return node;
     (void)hipGetLastError();
@@ -128,8 +126,9 @@ struct NodeAffinity {
     cpu_set_t prev;
     bool bound = false;
     int node = -1;
-    explicit NodeAffinity(int dev)
+    explicit NodeAffinity(int dev, bool enabled)
     {
+        if (!enabled) return;
         const NodeCpus &nc = node_cpus_of_device(dev);
         node = nc.node;
         if (!nc.have) return;
@@ -202,7 +201,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     HIP_TRY(hipSetDevice(dev));
     // this thread is the unit's feeder: it (and the drainer it starts, which inherits the affinity) runs on the device's CPU node, and
     // the pinned rings it allocates land there; the caller's affinity is restored on return
-    NodeAffinity node_guard(dev);
+    NodeAffinity node_guard(dev, o.host_numa == 0);
     DevCtx *c = nullptr;
     int rc = get_ctx(m, dev, &c);
     if (rc) return rc;

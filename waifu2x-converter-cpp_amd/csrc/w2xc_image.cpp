@@ -68,6 +68,18 @@ int process_image_device(w2xc_model *mn, DevCtx *cn, w2xc_model *msc, DevCtx *cs
     return W2XC_OK;
 }
 
+// Both contexts of a noise + scale call, taken TOGETHER (std::lock's deadlock avoidance): two threads that pass the same two models in opposite
+// roles -- (A as noise, B as scale) and (B as noise, A as scale) -- would otherwise each hold one mutex and wait for the other.
+void lock_contexts(DevCtx *cn, DevCtx *cs, std::unique_lock<std::mutex> &l1, std::unique_lock<std::mutex> &l2)
+{
+    if (cn && cs && cn != cs) {
+        l1 = std::unique_lock<std::mutex>(cn->mu, std::defer_lock);
+        l2 = std::unique_lock<std::mutex>(cs->mu, std::defer_lock);
+        std::lock(l1, l2);
+    } else if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
+    else if (cs) l1 = std::unique_lock<std::mutex>(cs->mu);
+}
+
 // resolve device + contexts of the (up to two) models and run the pipeline under their locks
 int process_image_locked(w2xc_model *mn, w2xc_model *msc, const unsigned char *d_in, size_t in_stride, int w, int h, unsigned char *d_out,
                          size_t out_stride, int iterations, double shrink, hipStream_t st, const w2xc_opts &o, int dev)
@@ -77,8 +89,7 @@ int process_image_locked(w2xc_model *mn, w2xc_model *msc, const unsigned char *d
     if (mn && (rc = get_ctx(mn, dev, &cn))) return rc;
     if (msc && (rc = get_ctx(msc, dev, &cs))) return rc;
     std::unique_lock<std::mutex> l1, l2;
-    if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
-    if (cs && cs != cn) l2 = std::unique_lock<std::mutex>(cs->mu);
+    lock_contexts(cn, cs, l1, l2);
     return process_image_device(mn, cn, msc, cs, d_in, in_stride, w, h, d_out, out_stride, iterations, shrink, st, o);
 }
 
@@ -157,8 +168,7 @@ try {
     if (noise_model && (rc = get_ctx(noise_model, dev, &cn))) return rc;
     if (scale_model && (rc = get_ctx(scale_model, dev, &cs))) return rc;
     std::unique_lock<std::mutex> l1, l2;
-    if (cn) l1 = std::unique_lock<std::mutex>(cn->mu);
-    if (cs && cs != cn) l2 = std::unique_lock<std::mutex>(cs->mu);
+    lock_contexts(cn, cs, l1, l2);
     DevCtx *c = cs ? cs : cn;
     const size_t in_bytes = ((size_t)w * 3 * h + 255) & ~(size_t)255, out_bytes = (size_t)W * 3 * H;
     if (c->img_io_bytes < in_bytes + out_bytes) {

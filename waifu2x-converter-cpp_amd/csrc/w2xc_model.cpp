@@ -32,29 +32,38 @@ static int g_block_w = 512, g_block_h = 512;
 
 int njob() { std::lock_guard<std::mutex> lk(g_util_mu); return g_njob; }
 
-w2xc_opts resolve_opts(const w2xc_opts *o)
+// what `opts == NULL` resolves to (w2xc_set_default_opts): w2xc_opts_init's defaults + the two environment variables the library reads
+static std::mutex g_defaults_mu;
+static w2xc_opts g_defaults;
+static bool g_defaults_set = false;
+static w2xc_opts env_defaults()
 {
     w2xc_opts r;
     w2xc_opts_init(&r);
+    // callers that pass no options (the C++ adapter behind the reference's CLI): the default precision can
+    // be switched without recompiling -- W2XC_PRECISION = fp32 | bf16x3 | fp16x2 | bf16x2 | bf16
+    if (const char *e = getenv("W2XC_PRECISION")) {
+        if (!strcmp(e, "bf16x3")) r.precision = W2XC_PRECISION_BF16X3;
+        else if (!strcmp(e, "bf16x2")) r.precision = W2XC_PRECISION_BF16X2;
+        else if (!strcmp(e, "fp16x2")) r.precision = W2XC_PRECISION_FP16X2;
+        else if (!strcmp(e, "bf16")) r.precision = W2XC_PRECISION_BF16;
+    }
+    if (const char *e = getenv("W2XC_FILTER_RESIDENT")) r.filter_resident = atoi(e) != 0 ? 1 : 0;
+    return r;
+}
+
+w2xc_opts resolve_opts(const w2xc_opts *o)
+{
+    w2xc_opts r;
     if (o) {
+        w2xc_opts_init(&r);
         size_t n = o->struct_size > 0 && (size_t)o->struct_size < sizeof(w2xc_opts) ? (size_t)o->struct_size : sizeof(w2xc_opts);
         memcpy(&r, o, n);
         r.struct_size = (int)sizeof(w2xc_opts);
     } else {
-        // callers that pass no options (the C++ adapter behind the reference's CLI): the default precision can
-        // be switched without recompiling -- W2XC_PRECISION = fp32 | bf16x3 | fp16x2 | bf16x2 | bf16
-        static const int env_prec = [] {
-            const char *e = getenv("W2XC_PRECISION");
-            if (!e) return W2XC_PRECISION_FP32;
-            if (!strcmp(e, "bf16x3")) return W2XC_PRECISION_BF16X3;
-            if (!strcmp(e, "bf16x2")) return W2XC_PRECISION_BF16X2;
-            if (!strcmp(e, "fp16x2")) return W2XC_PRECISION_FP16X2;
-            if (!strcmp(e, "bf16")) return W2XC_PRECISION_BF16;
-            return W2XC_PRECISION_FP32;
-        }();
-        r.precision = env_prec;
-        static const int env_res = [] { const char *e = getenv("W2XC_FILTER_RESIDENT"); return (e && atoi(e) != 0) ? 1 : 0; }();
-        r.filter_resident = env_res;
+        std::lock_guard<std::mutex> lk(g_defaults_mu);
+        if (!g_defaults_set) { g_defaults = env_defaults(); g_defaults_set = true; }
+        r = g_defaults;
     }
     return r;
 }
@@ -148,8 +157,76 @@ void w2xc_opts_init(w2xc_opts *o)
     o->device = -1;
 }
 
+void w2xc_opts_init_sized(w2xc_opts *o, size_t struct_size)
+{
+    if (!o || struct_size < 4 * sizeof(int)) return;   // (struct_size, precision, kernel, device: every version of the struct has them)
+    w2xc_opts full;
+    w2xc_opts_init(&full);
+    const size_t n = std::min(struct_size, sizeof(w2xc_opts));
+    full.struct_size = (int)n;
+    memcpy(o, &full, n);
+}
+
+int w2xc_set_default_opts(const w2xc_opts *defaults)
+{
+    w2xc_opts r;
+    if (defaults) {
+        w2xc_opts_init(&r);
+        const size_t n = defaults->struct_size > 0 && (size_t)defaults->struct_size < sizeof(w2xc_opts) ? (size_t)defaults->struct_size : sizeof(w2xc_opts);
+        memcpy(&r, defaults, n);
+        r.struct_size = (int)sizeof(w2xc_opts);
+    } else {
+        r = env_defaults();
+    }
+    std::lock_guard<std::mutex> lk(g_defaults_mu);
+    g_defaults = r;
+    g_defaults_set = true;
+    return W2XC_OK;
+}
+
 const char *w2xc_last_error(void) { return g_last_error.c_str(); }
-const char *w2xc_version(void) { return "w2xc_hip 0.1 (gfx950)"; }
+// 0.2: w2xc_opts grew (host_numa; 56 bytes), W2XC_FUSION_FIRST / _LAST, w2xc_opts_init_sized, w2xc_set_default_opts, w2xc_plan_rows; since 0.1 (rounds 3-5)
+// also: W2XC_KERNEL_WINOGRAD = _WINOGRAD32, W2XC_KERNEL_AUTO refused on a minimum-halo row view, `verbose` a bit mask (INTEGRATION.md "ABI history")
+const char *w2xc_version(void) { return "w2xc_hip 0.2 (gfx950)"; }
+
+int w2xc_plan_rows(const w2xc_model *m, int w, int view_y0, int view_h, int plane_h, int row_begin, int row_end, const w2xc_opts *opts, w2xc_row_plan *plan)
+try {
+    if (!m || !plan) return fail(W2XC_ERR_ARG, "null argument");
+    const int n = (int)m->layers.size();
+    if (w <= 0 || plane_h <= 0 || row_begin < 0 || row_end > plane_h || row_begin >= row_end)
+        return fail(W2XC_ERR_ARG, "bad row range [%d,%d) for a %d-row plane", row_begin, row_end, plane_h);
+    if (view_y0 < 0 || view_h <= 0 || view_y0 + view_h > plane_h || view_y0 > std::max(0, row_begin - n) || view_y0 + view_h < std::min(plane_h, row_end + n))
+        return fail(W2XC_ERR_ARG, "view rows [%d,%d) do not cover [%d,%d) +- %d halo rows", view_y0, view_y0 + view_h, row_begin, row_end, n);
+    RowPlan P;
+    int rc = plan_rows(m, resolve_opts(opts), w, view_h, view_y0, row_begin, row_end, plane_h, m->layers.empty() ? 1 : m->layers[0].nin, false, &P);
+    if (rc) return rc;
+    w2xc_row_plan r;
+    memset(&r, 0, sizeof r);
+    r.struct_size = (int)sizeof r;
+    r.n_layers = P.n;
+    r.halo_rows_per_layer = P.HL;
+    r.band_rows = P.band;
+    r.n_bands = (row_end - row_begin + P.band - 1) / P.band;
+    r.fused_first = (split_terms(P.o) ? fuse_first(m, P.o) : fuse_first_fp32(m, P.o)) ? 1 : 0;
+    r.fused_last = (split_terms(P.o) ? fuse_last(m, P.o) : fuse_last_fp32(m, P.o)) ? 1 : 0;
+    r.workspace_bytes[0] = P.need[0];
+    r.workspace_bytes[1] = P.need[1];
+    const size_t nb = plan->struct_size > 0 && (size_t)plan->struct_size < sizeof r ? (size_t)plan->struct_size : sizeof r;
+    r.struct_size = (int)nb;
+    memcpy(plan, &r, nb);
+    return W2XC_OK;
+} W2XC_CATCH_ALL
+
+int w2xc_plan_region(const w2xc_row_plan *plan, int plane_h, int layer, int y0, int y1, int *top, int *bottom)
+{
+    if (!plan || !top || !bottom || layer < 1 || layer > plan->n_layers || y0 >= y1) return fail(W2XC_ERR_ARG, "bad argument");
+    RowPlan P;
+    P.n = plan->n_layers;
+    P.HL = plan->halo_rows_per_layer;
+    P.plane_h = plane_h;
+    P.region(layer, y0, y1, *top, *bottom);
+    return W2XC_OK;
+}
 
 int w2xc_device_count(void)
 {

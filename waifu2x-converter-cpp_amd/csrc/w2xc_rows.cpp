@@ -116,112 +116,18 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
              float *d_out, size_t out_stride_f, hipStream_t st, const w2xc_opts &o_in, int up, int n_in,
              long long in_cs, long long out_cs, const BandHooks *hk, int plane_h)
 {
-    const int n = (int)m->layers.size();
-    if (n == 0) return fail(W2XC_ERR_ARG, "model has no layers");
-    // conv3x3_wino4 (F(4x4,3x3)): an output of a 4x4 block depends, at rounding level, on all 36 patch values, so a block cut by the edge of a
-    // band's region (clamped rows instead of the plane's) would make results depend on the banding.  HL = 4: every layer k < n computes the rows
-    //     [floor4(y0) - 4 (n - k), ceil4(y1) + 4 (n - k))  clipped to the layer's plane extent [-(n - k), H + (n - k))
-    // of a band [y0, y1) instead of [y0 - (n - k), y1 + (n - k)): every region edge that is not a plane edge is a block edge (blocks sit on rows
-    // = 0 mod 4 of the plane), and layer k + 1 finds the rows it reads (one more each side) inside.  Costs up to 3 + 3 (n - k) more rows per side.
-    w2xc_opts o = o_in;
-    int HL = 1;
-    if (uses_wino4(m, o)) {
-        const int hs = 4 * n;
-        if (plane_h > 0 && vy0 <= std::max(0, ra - hs) && vy0 + vh >= std::min(plane_h, rb + hs)) HL = 4;
-        else if (o.kernel == W2XC_KERNEL_AUTO)   // a view with n halo rows only: no silent change of kernel (and rounding) -- the caller decides
-            return fail(W2XC_ERR_ARG, "row-band view [%d,%d) of rows [%d,%d): the default F(4x4) kernel needs %d halo rows (4 per layer) for banding-invariant results; "
-                                      "pass the wide view or choose w2xc_opts.kernel explicitly (W2XC_KERNEL_WINOGRAD32: F(2x2), banding-invariant on the minimum view)",
-                        vy0, vy0 + vh, ra, rb, hs);
-        // (an explicit W2XC_KERNEL_WINOGRAD4 on a narrow view runs as asked: results then depend on the banding at rounding level)
-    }
-    auto region = [&](int k, int y0, int y1, int &T, int &B) {   // plane rows [T, B) layer k computes for the band [y0, y1)
-        if (HL == 1 || k == n) { T = y0 - (n - k); B = y1 + (n - k); return; }
-        T = std::max(-(n - k), (y0 & ~3) - 4 * (n - k));
-        B = std::min(plane_h + (n - k), ((y1 + 3) & ~3) + 4 * (n - k));
-    };
-    if (m->layers[0].nin != n_in)   // convertWithModelsBasic pushes exactly one plane (convertRoutine.cpp:63-64)
-        return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", n_in, m->layers[0].nin);
-    const bool all_out = out_cs != 0;   // multi-plane output
-    for (int l = 1; l < n; l++)
-        if (m->layers[l].nin != m->layers[l - 1].nout)
-            return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
-    const int T = split_terms(o);
-    if (o.precision != W2XC_PRECISION_FP32 && T == 0) return fail(W2XC_ERR_ARG, "unknown precision %d", o.precision);
-    if (T > 0)
-        for (int l = 0; l < n; l++)
-            if (layer_kind(m, l, o) == W2XC_K_DIRECT)
-                return fail(W2XC_ERR_UNSUPPORTED, "16-bit precision modes: layer %d (%d->%d) has no kernel ({1,3}->{32,64,128} first, {32,64,128}->{32,64,128}, ->{1,3} last only)",
-                            l + 1, m->layers[l].nin, m->layers[l].nout);
-    // bytes per activation element of layer k's output (k = 1..n) in the workspace
-    auto out_bpe = [&](int k) -> size_t {
-        const int ot = out_terms_of(m, k - 1, o);
-        return (ot >= 1 && ot <= 3) ? 2 * (size_t)ot : 4;
-    };
-
-    // the last layer stores straight into the caller's planar plane(s) when its kernel can address planar
-    // output (conv3x3_last / conv3x3_direct); otherwise it goes through the NHWC workspace + a repack
-    const W2xcKernelKind last_kind = layer_kind(m, n - 1, o);
-    const bool last_direct = (m->layers[n - 1].nout == 1 || all_out) &&
-                             (last_kind == W2XC_K_LAST || last_kind == W2XC_K_LAST_GATHER || last_kind == W2XC_K_DIRECT ||
-                              (m->layers[n - 1].nout == 1 && last_kind != W2XC_K_MFMA && last_kind != W2XC_K_FIRST));
-    // BYTES per band for the two ping-pong buffers (layer k output goes to ws[(k-1)&1])
-    auto ws_need = [&](int rows, size_t need[2]) {
-        need[0] = need[1] = 0;
-        for (int k = 1; k <= n; k++) {
-            if (k == n && last_direct) break;   // written straight to d_out
-            if (k == 1 && layer_kind(m, 0, o) == W2XC_K_FUSED_AWAY) continue;   // layer 1's activations stay on chip
-            const size_t hk = (size_t)rows + ((HL == 1 || k == n) ? 2 * (n - k) : 6 + 8 * (n - k)), wk = (size_t)w + 2 * (n - k);
-            const bool fused = out_terms_of(m, k - 1, o) == 9;   // partial G planes of the fused last layer
-            const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * out_bpe(k);
-            const size_t wk_mem = planar_between(m, k - 1, o) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows start on 128-byte lines
-            need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk_mem * px_bytes);
-        }
-    };
-    int band = o.band_rows;
-    const int total = rb - ra;
-    if (band <= 0) {
-        const size_t budget = (size_t)(o.workspace_mb > 0 ? o.workspace_mb : 16384) << 20;
-        size_t need[2];
-        ws_need(total, need);
-        if (need[0] + need[1] <= budget) band = total;
-        else {
-            // bytes grow linearly in rows: solve on two probes
-            size_t n1[2], n2[2];
-            ws_need(1, n1);
-            ws_need(2, n2);
-            const double per_row = (double)((n2[0] + n2[1]) - (n1[0] + n1[1]));
-            const double base = (double)(n1[0] + n1[1]) - per_row;
-            band = (int)std::floor(((double)budget - base) / per_row);
-            if (band < 1) band = 1;
-            if (band > total) band = total;
-            // each buffer's need is a MAX over layers, so the slope measured at 1..2 rows is that of the wide-halo,
-            // few-plane layers and under-estimates large bands: re-evaluate the real need and shrink until it fits
-            for (int it = 0; it < 64 && band > 1; it++) {
-                ws_need(band, need);
-                if (need[0] + need[1] <= budget) break;
-                const int nb2 = (int)((double)band * (double)budget / (double)(need[0] + need[1]));
-                band = std::max(1, std::min(band - 1, nb2));
-            }
-            const int nb = (total + band - 1) / band;
-            band = (total + nb - 1) / nb;   // equalise (never larger than the band that was just checked)
-        }
-    }
-    if (fuse_first_fp32(m, o)) {
-        // conv3x3_first2_wino4 addresses its 32 output planes with 32-bit lane offsets (12 plane strides + a row): planes of at most 64 Mi floats
-        const size_t wk = ((size_t)w + 2 * (n - 2) + 31) & ~(size_t)31;
-        const size_t max_rows = ((size_t)64 << 20) / wk;
-        const size_t halo = HL == 1 ? 2 * (size_t)(n - 2) : 6 + 8 * (size_t)(n - 2);
-        if (max_rows < halo + 8) return fail(W2XC_ERR_UNSUPPORTED, "plane too wide (%d pixels) for the fused first layers; use w2xc_opts.fusion = W2XC_FUSION_OFF", w);
-        if ((size_t)band + halo > max_rows) band = (int)(max_rows - halo);
-    }
-    if (HL > 1 && band < total) band = std::max(4, band & ~3);   // (band edges on block rows: no rounding-out rows)
-    band = std::min(band, total);
+    RowPlan P;
     {
-        size_t need[2];
-        ws_need(band, need);
-        for (int i = 0; i < 2; i++)
-            if (need[i]) { int rc = ensure_ws(c, i, (need[i] + 3) / 4); if (rc) return rc; }
+        int rc = plan_rows(m, o_in, w, vh, vy0, ra, rb, plane_h, n_in, out_cs != 0, &P);
+        if (rc) return rc;
     }
+    const w2xc_opts &o = P.o;
+    const int n = P.n, HL = P.HL, T = P.T, band = P.band;
+    const bool all_out = P.all_out, last_direct = P.last_direct;   // (all_out: multi-plane output)
+    const W2xcKernelKind last_kind = P.last_kind;
+    auto region = [&](int k, int y0, int y1, int &Tk_, int &Bk_) { P.region(k, y0, y1, Tk_, Bk_); };
+    for (int i = 0; i < 2; i++)
+        if (P.need[i]) { int rc = ensure_ws(c, i, (P.need[i] + 3) / 4); if (rc) return rc; }
 
     for (int y0 = ra; y0 < rb; y0 += band) {
         const int y1 = std::min(rb, y0 + band);
@@ -433,13 +339,17 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 // the upload of rows [c0 + 2 + off_y ...] and layer 1 of the rows before them overlap: what stays exposed of the
                 // input side is the first slice and the last chunk, not upload + layer 1 back to back.  (Layers 1 + 2 in one launch: the same,
                 // two rows deeper; chunks of whole 8-row tiles keep the 4x4 blocks where the unchunked launch has them.)
-                const int reach = kind == W2XC_K_FIRST2_WINO4 ? 4 : 2;
                 for (int c0 = 0; c0 < d.out_h; c0 += in_chunk) {
                     W2xcConvDesc dd = d;
                     dd.out_h = std::min(in_chunk, d.out_h - c0);
                     dd.out = d.out + (size_t)c0 * d.out_rs;
                     dd.off_y = d.off_y + c0;
-                    const int vlast = std::min(std::max(c0 + dd.out_h - 1 + reach + d.off_y, 0), d.in_h - 1);   // last view row this chunk reads
+                    // last view row this chunk reads.  Layer 1 alone: its last row + 2.  The fused launch: the chunk ends on a multiple of 8 LOCAL rows, which
+                    // is a 4x4-block edge only when wino_py = 0; the block that straddles the end reads its whole 6-row patch -- every row of it enters every
+                    // output row of the block at rounding level (and as NaN if the row holds one) -- so the wait covers the last TOUCHED block: its last row + 4
+                    int last = c0 + dd.out_h - 1 + 2;
+                    if (kind == W2XC_K_FIRST2_WINO4) last = (((c0 + dd.out_h + d.wino_py + 3) & ~3) - d.wino_py) - 1 + 4;
+                    const int vlast = std::min(std::max(last + d.off_y, 0), d.in_h - 1);
                     int rc = hk->input_upto(vlast);
                     if (rc) return rc;
                     rc = launch_layer(c, m, k - 1, kind, dd, st, o);
