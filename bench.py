@@ -96,7 +96,7 @@ def pmc_traffic(kernel, cin, cout, H, W, precision="fp32"):
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/make_profile_summary.py).  rocprofv3 cannot
     run inside this process, so this is the profile of the SAME command -- valid only for the sources it was taken
     from: returns (bytes, note)."""
-    rel = "profiles/r5_roofline.json" if precision == "fp32" else "profiles/r5_%s_roofline.json" % precision
+    rel = "profiles/r6_roofline.json" if precision == "fp32" else "profiles/r6_%s_roofline.json" % precision
     path = os.path.join(ROOT, rel)
     try:
         prof = json.load(open(path))
@@ -495,7 +495,38 @@ def main():
                                         "resident_ms": round(tr * 1e3, 2), "resident_Mpix_s": round(8192 * 8192 / tr / 1e6, 3),
                                         "host_to_host_ms_median": round(statistics.median(tb) * 1e3, 2),
                                         "host_to_host_Mpix_s": round(8192 * 8192 / statistics.median(tb) / 1e6, 3),
+                                        "host_to_host_ratio_vs_resident": round(tr / statistics.median(tb), 4),
                                         "host_output_finite": bool(np.isfinite(outb[::97, ::89]).all())}
+                # the like-for-like denominator of a 1 -> N scaling curve: `--gpus N` (N > 1) shards THIS plane, so its N-GPU `value` divides
+                # by this figure, not by the 1080p `value` above (the N > 1 line re-measures it on rank 0 and carries the quotient itself)
+                extras["scale_reference"] = {"workload": "plane_8192 (BASELINE.json configs[2], what --gpus N > 1 shards), ONE GPU, planes resident",
+                                             "Mpix_s": extras["plane_8192"]["resident_Mpix_s"], "ms_per_step": extras["plane_8192"]["resident_ms"]}
+                # what ONE host sustains when it feeds eight units (an 8-GPU node's host side, here on the device(s) present): the same plane
+                # through w2xc_opts.host_units = 8 with a ONE-layer 1 -> 1 model -- pageable plane -> pinned ring -> H2D and D2H -> pinned ring ->
+                # pageable plane with nJob staging threads, a fraction of a millisecond of kernel time per unit
+                try:
+                    tiny = w2xc._ModelSet.from_layers(gen_model.synth_layers([1, 1], 3))
+                    o8 = w2xc.make_opts(device=dev_index, device_mask=1 << dev_index, host_units=8)
+
+                    def call_farm():
+                        rc = lib.w2xc_convert_plane_nn2x(tiny.handle, yb.ctypes.data, yb.strides[0], 8192, 8192, outb.ctypes.data, outb.strides[0], C.byref(o8))
+                        if rc != 0:
+                            raise RuntimeError(w2xc.last_error())
+                    call_farm()
+                    tf = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        call_farm()
+                        tf.append(time.perf_counter() - t0)
+                    moved = yb.nbytes + outb.nbytes
+                    extras["host_farm_8units_GBps"] = round(moved / min(tf) / 1e9, 2)
+                    extras["host_farm_8units"] = {"seconds": round(min(tf), 4), "bytes_in_plus_out": moved, "njob": njobs, "devices": 1,
+                                                  "note": "eight units' scatter + gather through the staging rings of ONE device (units on a shared device "
+                                                          "serialise): a lower bound on what an 8-GPU node's host side sustains; the 16384^2 plane's "
+                                                          "compute share per GPU at N = 8 is ~57 ms"}
+                    del tiny
+                except Exception as e:
+                    extras["host_farm_8units_error"] = repr(e)
                 del d_yb, d_ob, outb, yb
             elif world > 1 and sharded:
                 # weak scaling beside the strong-scaling headline: every rank converts its own 1080p frame
@@ -505,6 +536,31 @@ def main():
                 extras["weak"] = {"workload": "scale2x_1080p: one 1920x1080 frame per rank per step (BASELINE.json configs[1] x N)",
                                   "value": round(world * 1080 * 1920 * args.steps / tw / 1e6, 4), "unit": "Mpix/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
                                   "scaling": "weak"}
+                del dw_in, dw_out
+                # the like-for-like denominator of THIS line's `value`: the same plane, whole, on rank 0's GPU alone (the other ranks wait at the
+                # next barrier; outside every timed region).  scaling_efficiency = value / (N x this) -- the N = 1 line's 1080p `value` is another workload
+                if dist is not None:
+                    dist.barrier()
+                if rank == 0:
+                    yb = y_src
+                    d_yb = torch.from_numpy(np.ascontiguousarray(yb)).cuda()
+                    d_ob = torch.empty((H, W), dtype=torch.float32, device="cuda")
+                    o1 = mk_opts(0)
+                    run1 = lambda: ms.convert_nn2x_device(d_yb.data_ptr(), in_w * 4, in_w, in_h, d_ob.data_ptr(), W * 4, stream=stream.cuda_stream, opts=o1)
+                    run1()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        run1()
+                    torch.cuda.synchronize()
+                    t1 = (time.perf_counter() - t0) / 2
+                    ref = in_h * in_w / t1 / 1e6
+                    extras["scale_reference"] = {"workload": "the same %dx%d frame, whole, on ONE GPU (rank 0 alone), planes resident" % (in_w, in_h),
+                                                 "Mpix_s": round(ref, 3), "ms_per_step": round(t1 * 1e3, 2)}
+                    extras["scaling_efficiency"] = round((in_h * in_w * args.steps / elapsed / 1e6) / (world * ref), 4)
+                    extras["scaling_efficiency_is"] = "value / (n_gpus x scale_reference.Mpix_s): same plane, same run, same box%s" % (
+                        "" if len(set(int(v) for v in rank_dev)) == world else " -- RANKS SHARE A DEVICE here (self-test): not a scaling figure")
+                    del d_yb, d_ob
         except Exception as e:   # never let a side measurement break the headline line
             extras["extras_error"] = repr(e)
     if not args.no_extras and world == 1 and workload == "scale2x_1080p":
@@ -605,9 +661,12 @@ def main():
                       "fp16x2": "f32 values as 2 fp16 terms (3 fp16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision",
                       "bf16x3": "f32 values as 3 bf16 terms (6 bf16 MFMA products per multiply-add, f32 accumulate) in layers 2..n-1; not the headline precision"}[args.precision],
             "data": "synthetic",
-            "value_is": "planes resident in HBM when the timed region starts (bench contract); the PCIe-inclusive host->host figure is `host_to_host`",
+            "value_is": ("`value` = planes resident in HBM when the timed region starts, as the bench contract defines it (a PCIe-inclusive rate is never `value`). "
+                         "BASELINE.json's metric says END-TO-END, which SURVEY 8(d) defines as host plane in -> host plane out (what main.cpp:148 brackets): "
+                         "that is `value_end_to_end` (= `value_host_to_host`, pageable planes), measured in the same run; quote it first wherever 'end-to-end' is meant"),
             "value_resident": round(value, 4),
             "value_host_to_host": host["pageable"]["Mpix_s"] if host else None,
+            "value_end_to_end": host["pageable"]["Mpix_s"] if host else None,
             "config": {"workload": wl_name + ": scale2.0x topology (1-32-32-64-64-128-128-1, synthetic seeded weights) on a "
                                    "%dx%d RGB frame -> Y plane nearest-2x -> %dx%d CNN plane, %s" %
                                    (in_w, in_h, W, H, ("ONE frame per step, rank r computes rows [H*r/N, H*(r+1)/N) (+7-row halo), no exchange" if sharded

@@ -111,6 +111,12 @@ typedef struct w2xc_opts {
 #define W2XC_FUSION_ON    2
 #define W2XC_FUSION_FIRST 3   /* only layers 1 + 2 in one launch */
 #define W2XC_FUSION_LAST  4   /* only the last layer inside the epilogue of the layer before it */
+/* Round 6: where the fused last layer is FINISHED.  The host-pointer entry points let the launch of layer n - 1 finish it itself, in row order
+ * (conv3x3_wino4 PROG: its gather jobs write the output rows straight into page-locked host memory and flag them, so rows leave for the caller's plane
+ * while the launch is still running); the device-pointer entry points follow it with a conv3x3_last_gather launch (0.2 ms faster when nothing waits
+ * for rows).  Both are the same sum in the same order: BIT-identical.  For A/B runs and tests: */
+#define W2XC_FUSION_GATHER_LAUNCH 5   /* as AUTO, but the gather launch in every entry point (the form of rounds 4 / 5) */
+#define W2XC_FUSION_PROG          6   /* as AUTO, but finished inside the producing launch in every entry point        */
 
 /* Fill *o with defaults (fp32, auto kernels, current device, all devices, auto banding).  Writes sizeof(w2xc_opts) bytes of THIS header's
  * struct: a binary compiled against an older, shorter w2xc_opts must call w2xc_opts_init_sized with ITS sizeof (or be rebuilt) --

@@ -203,8 +203,10 @@ def test_argument_validation(w2xc, noise1_layers):
     assert ms.kernel_name(0, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_first" and ms.kernel_name(1, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_wino"
     assert ms.kernel_name(1, w2xc.make_opts(kernel=w2xc.KERNEL_MFMA)) == "conv3x3_mfma" and ms.kernel_name(1, w2xc.make_opts(kernel=w2xc.KERNEL_DIRECT)) == "conv3x3_direct"
     # the one-plane last layer: inside conv3x3_wino4's epilogue (+ the tap gather) unless fusion is off or another mid kernel runs layer 6
-    fused = True   # W2XC_FUSION_AUTO = on
-    assert ms.kernel_name(6) == ("conv3x3_last_gather" if fused else "conv3x3_last")
+    # (round 6: the 128 -> 128 launch finishes it too -- conv3x3_wino4 PROG -- so the layer has no launch; W2XC_FUSION_GATHER_LAUNCH = the separate gather of rounds 4 / 5)
+    assert ms.kernel_name(6) == "conv3x3_last_gather"      # (the device entry points; the host entry points let the 128 -> 128 launch finish the layer: W2XC_FUSION_PROG everywhere)
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_PROG)) == "(in_previous_layer)"
+    assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_GATHER_LAUNCH)) == "conv3x3_last_gather"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_OFF)) == "conv3x3_last"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD4)) == "conv3x3_last_gather"
     assert ms.kernel_name(6, w2xc.make_opts(fusion=w2xc.FUSION_ON, kernel=w2xc.KERNEL_WINOGRAD)) == "conv3x3_last"   # (the F(2x2) kernel has no fused epilogue)

@@ -5,6 +5,8 @@ w2xc_opts.kernel, so all of them run in this one process.  (The round-3 F(2x2) k
 import numpy as np
 import pytest
 
+from conftest import assert_close, rand_plane, small_layers
+
 pytestmark = pytest.mark.gpu
 
 
@@ -106,16 +108,24 @@ def test_fused_last_layer_fp32_vs_unfused(gpu, planes, mid):
     n = len(planes) - 1
     kern = gpu.KERNEL_WINOGRAD4
     on, off = gpu.make_opts(fusion=gpu.FUSION_ON, kernel=kern), gpu.make_opts(fusion=gpu.FUSION_OFF, kernel=kern)
+    # (the launch of layer n - 1 also FINISHES the last layer where conv3x3_wino4 PROG has an instantiation -- planar 64 / 128-plane inputs; a gather launch follows otherwise)
+    # (the host entry points let the launch of layer n - 1 FINISH the last layer where conv3x3_wino4 PROG has an instantiation -- planar 64 / 128-plane inputs --,
+    #  the device entry points -- which kernel_name describes -- only with W2XC_FUSION_PROG; a gather launch follows otherwise.  Bit-identical either way.)
     assert ms.kernel_name(n - 1, on) == "conv3x3_last_gather" and ms.kernel_name(n - 2, on) == mid
     assert ms.kernel_name(n - 1, off) == "conv3x3_last"
     if mid == "conv3x3_wino4":   # ... and it is what the default options run
         assert ms.kernel_name(n - 1) == "conv3x3_last_gather" and ms.kernel_name(n - 2) == mid
+    sep = gpu.make_opts(fusion=gpu.FUSION_GATHER_LAUNCH, kernel=kern)   # the gather launch in the host entry point too
+    assert ms.kernel_name(n - 1, sep) == "conv3x3_last_gather"
+    has_prog = planes[-3] in (64, 128) and len(planes) > 4
+    assert ms.kernel_name(n - 1, gpu.make_opts(fusion=gpu.FUSION_PROG, kernel=kern)) == ("(in_previous_layer)" if has_prog else "conv3x3_last_gather")
     gate = 4e-5   # (the max-norm gate of the F(4x4) kernel on short models, test_wino4_f4x4_kernel)
     o = orc.Oracle(layers)
     worst = 0.0
     for (h, wd) in ((37, 61), (8, 32), (300, 170), (1, 1), (16, 33)):
         x = np.random.default_rng(h * 11 + wd).random((h, wd), dtype=np.float32)
         a, b = ms.convert(x, opts=on), ms.convert(x, opts=off)
+        assert np.array_equal(a, ms.convert(x, opts=sep)), ("gather in the launch vs gather launch", planes, h, wd)
         worst = max(worst, float(np.abs(a - b).max() / np.abs(b).max()))
         for band in (1, 7, 64):
             assert np.array_equal(a, ms.convert(x, opts=gpu.make_opts(fusion=gpu.FUSION_ON, kernel=kern, band_rows=band))), ("banding", planes, h, wd, band)
@@ -232,3 +242,61 @@ def test_wino4_whole_frame_vs_direct_mfma(gpu):
     err = float(np.abs(a - d).max() / np.abs(d).max())
     print("conv3x3_wino4 whole frame vs conv3x3_mfma2: %.2e of the output range" % err)
     assert np.isfinite(a).all() and err <= 2e-5, err
+
+
+def device_convert(gpu, ms, x, **okw):
+    import torch
+    h, wd = x.shape
+    d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    d_out = torch.empty_like(d_in)
+    st = torch.cuda.current_stream()
+    ms.convert_device(d_in.data_ptr(), wd * 4, wd, h, d_out.data_ptr(), wd * 4, stream=st.cuda_stream, opts=gpu.make_opts(device=0, **okw))
+    st.synchronize()
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.parametrize("planes", [[1, 32, 32, 64, 64, 128, 128, 1], [1, 32, 32, 64, 64, 1], [1, 32, 64, 128, 64, 1], [1, 32, 128, 128, 1]])
+def test_last_layer_finished_inside_the_producing_launch(gpu, planes):
+    """conv3x3_wino4 PROG (round 6): the launch of layer n - 1 writes its partial tap planes through to memory, every workgroup counts its arrival on the
+    16-row x 256-column gather jobs its tile feeds, and the workgroup whose arrival completes a job sums it -- the last layer is finished inside the launch,
+    rows complete top to bottom (what lets the host pipeline ship rows while layer n - 1 is still running; the stitch of convertRoutine.cpp:143-161).
+    Same sum in the same order as conv3x3_last_gather (w2xc_opts.fusion = W2XC_FUSION_GATHER_LAUNCH): BIT-identical for every size -- planes smaller than a
+    tile, one tile column, widths that are no multiple of 4 / 32 / 256 (ragged quads, ragged job groups, XCD bands of unequal width), more tile rows than a
+    dither period, bandings, row shards with the wide halo, the nearest-2x entry -- and repeatable (the job counters restart with every launch)."""
+    layers = small_layers(planes, 300 + len(planes))
+    ms = gpu._ModelSet.from_layers(layers)
+    n = len(planes) - 1
+    prog, sep = gpu.make_opts(fusion=gpu.FUSION_PROG), gpu.make_opts(fusion=gpu.FUSION_GATHER_LAUNCH)
+    assert ms.kernel_name(n - 1, prog) == "(in_previous_layer)" and ms.kernel_name(n - 1, sep) == "conv3x3_last_gather"
+    assert ms.kernel_name(n - 1) == "conv3x3_last_gather"   # (what the device entry points launch by default; ms.convert below is the HOST entry: PROG by default)
+    for (h, wd) in ((1, 1), (5, 3), (16, 32), (17, 33), (40, 257), (150, 290), (333, 1000), (131, 2051), (700, 70)):
+        x = rand_plane(h, wd, h * 7 + wd)
+        want = ms.convert(x, opts=sep)
+        for rep in range(2):
+            assert np.array_equal(ms.convert(x, opts=prog), want), (planes, h, wd, rep)            # host entry: rows over PCIe, followed by the drainer
+            assert np.array_equal(ms.convert(x), want), (planes, h, wd, rep, "default host path")
+        assert np.array_equal(device_convert(gpu, ms, x, fusion=gpu.FUSION_PROG), want), (planes, h, wd, "device entry")
+        assert np.array_equal(device_convert(gpu, ms, x), want), (planes, h, wd, "device entry, gather launch")
+        for band in (16, 100):
+            if band < h:
+                assert np.array_equal(ms.convert(x, opts=gpu.make_opts(band_rows=band)), want), (planes, h, wd, band)
+                assert np.array_equal(device_convert(gpu, ms, x, fusion=gpu.FUSION_PROG, band_rows=band), want), (planes, h, wd, band, "device entry")
+        assert np.array_equal(ms.convert_nn2x(x[:60, :70], opts=prog), ms.convert_nn2x(x[:60, :70], opts=sep))
+    # against the oracle on one size, and row shards with the wide halo through the device entry point
+    import torch
+    from oracle import oracle as orc
+    x = rand_plane(300, 417, 9)
+    want = ms.convert(x, opts=sep)
+    assert_close(want, orc.Oracle(layers).convert(x, njob=8), "gather launch vs oracle")
+    h, wd = x.shape
+    out = np.empty_like(x)
+    for p in range(3):
+        ra, rb = gpu.shard_rows(h, 3, p)
+        y0, y1 = gpu.shard_view(h, ra, rb, 4 * n)
+        d_view = torch.from_numpy(np.ascontiguousarray(x[y0:y1])).cuda()
+        d_out = torch.empty((rb - ra, wd), dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream()
+        ms.convert_rows_device(d_view.data_ptr(), wd * 4, y1 - y0, y0, wd, h, ra, rb, d_out.data_ptr(), wd * 4, stream=st.cuda_stream, opts=gpu.make_opts(device=0, fusion=gpu.FUSION_PROG))
+        st.synchronize()
+        out[ra:rb] = d_out.cpu().numpy()
+    assert np.array_equal(out, want)

@@ -30,7 +30,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libw2xc_hip.so")
 OK, ERR_IO, ERR_JSON, ERR_ARG, ERR_PLANES, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 PRECISION_FP32, PRECISION_BF16, PRECISION_BF16X2, PRECISION_BF16X3, PRECISION_FP16X2 = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MFMA, KERNEL_WINOGRAD, KERNEL_WINOGRAD32, KERNEL_WINOGRAD4 = 0, 1, 2, 3, 4, 5
-FUSION_AUTO, FUSION_OFF, FUSION_ON, FUSION_FIRST, FUSION_LAST = 0, 1, 2, 3, 4
+FUSION_AUTO, FUSION_OFF, FUSION_ON, FUSION_FIRST, FUSION_LAST, FUSION_GATHER_LAUNCH, FUSION_PROG = 0, 1, 2, 3, 4, 5, 6
 
 
 class W2xcError(RuntimeError):

@@ -90,6 +90,12 @@ struct HostPipe {
     size_t in_slot_bytes = 0, out_slot_bytes = 0;
     hipEvent_t ev_in_slot[IN_SLOTS] = {}, ev_out_slot[OUT_SLOTS] = {};   // last DMA that used the slot
     hipEvent_t ev_input = nullptr, ev_chunk = nullptr;                   // band input landed / last-layer chunk computed
+    // conv3x3_wino4 PROG: two page-locked band buffers the gather jobs write the output rows into over PCIe (bands alternate), and their job flags
+    char *pin_band[2] = {nullptr, nullptr};
+    size_t band_bytes[2] = {0, 0};
+    unsigned *pin_flags[2] = {nullptr, nullptr};
+    size_t flags_n[2] = {0, 0};
+    unsigned flags_epoch[2] = {0, 0};
     bool ready = false;
 
     void destroy()
@@ -105,6 +111,10 @@ struct HostPipe {
         if (d_out) { hipFree(d_out); d_out = nullptr; d_out_bytes = 0; }
         if (pin_in) { hipHostFree(pin_in); pin_in = nullptr; in_slot_bytes = 0; }
         if (pin_out) { hipHostFree(pin_out); pin_out = nullptr; out_slot_bytes = 0; }
+        for (int i = 0; i < 2; i++) {
+            if (pin_band[i]) { hipHostFree(pin_band[i]); pin_band[i] = nullptr; band_bytes[i] = 0; }
+            if (pin_flags[i]) { hipHostFree(pin_flags[i]); pin_flags[i] = nullptr; flags_n[i] = 0; flags_epoch[i] = 0; }
+        }
         if (s_compute) { hipStreamDestroy(s_compute); s_compute = nullptr; }
         if (s_h2d) { hipStreamDestroy(s_h2d); s_h2d = nullptr; }
         if (s_d2h) { hipStreamDestroy(s_d2h); s_d2h = nullptr; }
@@ -139,6 +149,8 @@ struct DevCtx {
     size_t ws_floats[2] = {0, 0};
     HostPipe pipe;
     FilterCache fc;
+    unsigned *prog_cnt = nullptr;   // conv3x3_wino4 PROG: gather-job counters of the launch in flight (grow-only)
+    size_t prog_cnt_n = 0;
     float *aux = nullptr;       // N2: Y/U/V planes of the image pipeline
     size_t aux_floats = 0;
     unsigned char *img_io = nullptr;   // N2, host entry points: device copies of the uint8 image in / out (grow-only)
@@ -178,6 +190,7 @@ struct DevCtx {
         for (int i = 0; i < 2; i++)
             if (ws[i]) hipFree(ws[i]);
         if (aux) hipFree(aux);
+        if (prog_cnt) hipFree(prog_cnt);
         if (img_io) hipFree(img_io);
         for (auto &e : pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto &e : pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -230,6 +243,7 @@ int layer_mid_variant(const w2xc_model *m, int l, const w2xc_opts &o);
 bool uses_wino4(const w2xc_model *m, const w2xc_opts &o);
 bool planar_between(const w2xc_model *m, int l, const w2xc_opts &o);
 int out_terms_of(const w2xc_model *m, int l, const w2xc_opts &o);
+bool gather_in_producer(const w2xc_model *m, const w2xc_opts &o);
 int fused_halves(int T, int cout);
 enum MidVariant { MID_MFMA = 0, MID_WINO32 = 1, MID_WINO4 = 3 };
 
@@ -262,6 +276,13 @@ struct BandHooks {
     std::function<int(int)> input_upto;
     std::function<int(int, int)> prefetch;               // layers 1..n-1 of the current band are enqueued; [y0, y1) = the NEXT band
     std::function<int(int, int)> output_ready;           // output rows [r0, r1) have been enqueued on the launch stream
+    // conv3x3_wino4 PROG (the launch of layer n - 1 finishes the last layer itself, rows completing in order): prog_begin hands out where the band's output
+    // rows [y0, y1) go -- page-locked host memory the kernel writes over PCIe -- and the job flags (tile_rows x groups words) with the value a finished job
+    // stores; out == nullptr on return: not available, the chunked path runs.  prog_launched: the launch is enqueued; job (jr, jg) holds the band's rows
+    // [16 jr - first, 16 jr - first + 16) clipped, columns [256 jg, 256 jg + 256).
+    struct ProgTail { float *out = nullptr; long long out_stride_f = 0; unsigned *flags = nullptr; unsigned epoch = 0; };
+    std::function<int(int, int, int, int, ProgTail *)> prog_begin;
+    std::function<int(int, int, int, int, int)> prog_launched;
 };
 
 int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, int vh, int vy0, int w, int ra, int rb,

@@ -269,11 +269,15 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     auto band_src_end = [&](int y1) { return overlap ? svh : ((std::min(H, y1 + hs) + up) >> up) - sy0; };
 
     // ---- output side ----
-    struct Chunk { int r0, r1, slot; };
+    // slot >= 0: rows [r0, r1) arrive in staging slot `slot` behind its D2H event.  slot < 0: a band whose last layer the launch of layer n - 1 finishes itself
+    // (conv3x3_wino4 PROG): its gather jobs write the rows into the page-locked band buffer `src` over PCIe and flag them (job (jr, jg) = rows
+    // [16 jr - first, 16 jr - first + 16) x columns [256 jg, 256 jg + 256) of the band); the drainer follows the flags and stitches rows while the launch runs
+    struct Chunk { int r0, r1, slot; int trows = 0, groups = 0, first = 0; const volatile unsigned *flags = nullptr; unsigned epoch = 0; const char *src = nullptr; };
     std::mutex qmu;
     std::condition_variable qcv;
     std::deque<Chunk> pending;     // D2H queued, not yet stitched (drainer consumes in order)
     long queued = 0, drained = 0;  // chunk counters (slots are used round-robin)
+    long prog_bands = 0, prog_bands_drained = 0;   // PROG bands handed to the drainer / stitched (the band buffers alternate)
     bool feeder_done = false;
     std::atomic<int> drain_rc{W2XC_OK};
     std::string drain_err;
@@ -289,6 +293,58 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                     if (pending.empty()) return;
                     ch = pending.front();
                     pending.pop_front();
+                }
+                if (ch.slot < 0) {
+                    // follow the job flags: tile rows complete top to bottom (roughly); every run of finished tile rows is stitched at once
+                    const int R = ch.r1 - ch.r0;
+                    int jr = 0;
+                    long spins = 0;
+                    bool launch_over = false;
+                    while (jr < ch.trows && drain_rc.load() == W2XC_OK) {
+                        int ready = jr;
+                        while (ready < ch.trows) {
+                            bool all = true;
+                            for (int g = 0; g < ch.groups && all; g++) all = (int)(ch.flags[(size_t)ready * ch.groups + g] - ch.epoch) >= 0;
+                            if (!all && !launch_over) break;
+                            ready++;
+                        }
+                        if (ready == jr) {
+                            // nothing new: the launch may be over (every row written, the flags' last stores included -- or it failed)
+                            if ((++spins & 1023) == 0) {
+                                const hipError_t q = hipStreamQuery(p.s_compute);
+                                if (q == hipSuccess) launch_over = true;
+                                else if (q != hipErrorNotReady) {
+                                    drain_err = std::string("the launch that finishes the last layer failed: ") + hipGetErrorString(q);
+                                    drain_rc.store(W2XC_ERR_HIP);
+                                }
+                            }
+#if defined(__x86_64__)
+                            __builtin_ia32_pause();
+#endif
+                            continue;
+                        }
+                        std::atomic_thread_fence(std::memory_order_acquire);
+                        const int a = std::max(0, 16 * jr - ch.first), b = std::min(R, 16 * ready - ch.first);
+                        if (b > a) {
+                            try {
+                                w2xc_host::CopyPool::get().copy_rows((char *)out + (size_t)(ch.r0 + a) * out_stride, out_stride, ch.src + (size_t)a * out_row, out_row, out_row,
+                                                                     b - a, copy_threads);
+                            } catch (const std::exception &ex) {
+                                drain_err = std::string("host copy of finished rows failed: ") + ex.what();
+                                drain_rc.store(W2XC_ERR_NOMEM);
+                            } catch (...) {
+                                drain_err = "host copy of finished rows failed";
+                                drain_rc.store(W2XC_ERR_NOMEM);
+                            }
+                        }
+                        jr = ready;
+                    }
+                    {
+                        std::lock_guard<std::mutex> ql(qmu);
+                        prog_bands_drained++;
+                    }
+                    qcv.notify_all();
+                    continue;
                 }
                 if (drain_rc.load() == W2XC_OK) {
                     hipError_t e = hipEventSynchronize(p.ev_out_slot[ch.slot]);
@@ -381,6 +437,62 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
             }
             qcv.notify_all();
         }
+        return W2XC_OK;
+    };
+
+    // conv3x3_wino4 PROG: the band's rows are written by the launch of layer n - 1 itself, into the caller's plane when it is page-locked, else into one of
+    // two page-locked band buffers (bands alternate; band s waits for band s - 2 to have been stitched), and flagged per job for the drainer
+    hk.prog_begin = [&](int y0, int y1, int trows, int groups, BandHooks::ProgTail *pt) -> int {
+        if (o.fusion == W2XC_FUSION_GATHER_LAUNCH) return W2XC_OK;   // (pt->out stays null: the chunked launches + gather of rounds 4 / 5)
+        if (out_pinned) {   // nothing to stitch: the rows are complete when the launch is (the closing synchronisation)
+            pt->out = (float *)((char *)out + (size_t)y0 * out_stride);
+            pt->out_stride_f = (long long)(out_stride / 4);
+            pt->flags = nullptr;
+            return W2XC_OK;
+        }
+        const int par = (int)(prog_bands & 1);
+        const size_t need = (size_t)(y1 - y0) * out_row, nflags = (size_t)trows * groups;
+        if (p.band_bytes[par] < need) {
+            HIP_TRY(hipStreamSynchronize(p.s_compute));   // (an earlier launch may still write the old buffer)
+            if (p.pin_band[par]) { HIP_TRY(hipHostFree(p.pin_band[par])); p.pin_band[par] = nullptr; p.band_bytes[par] = 0; }
+            // (COHERENT: uncached on the GPU side, every store goes out over PCIe at once -- default host allocations may be cached in the GPU's L2 until the launch
+            //  ends: the system-scope flag then arrived long before the rows it announces, measured)
+            if (hipHostMalloc((void **)&p.pin_band[par], need, hipHostMallocCoherent) != hipSuccess) return fail(W2XC_ERR_NOMEM, "hipHostMalloc(%zu MiB) of the band buffer failed", need >> 20);
+            p.band_bytes[par] = need;
+        }
+        if (p.flags_n[par] < nflags) {
+            HIP_TRY(hipStreamSynchronize(p.s_compute));
+            if (p.pin_flags[par]) { HIP_TRY(hipHostFree(p.pin_flags[par])); p.pin_flags[par] = nullptr; p.flags_n[par] = 0; }
+            if (hipHostMalloc((void **)&p.pin_flags[par], nflags * sizeof(unsigned), hipHostMallocCoherent) != hipSuccess) return fail(W2XC_ERR_NOMEM, "hipHostMalloc of the job flags failed");
+            memset(p.pin_flags[par], 0, nflags * sizeof(unsigned));
+            p.flags_n[par] = nflags;
+            p.flags_epoch[par] = 0;
+        }
+        {   // the buffer's previous band has been stitched
+            std::unique_lock<std::mutex> ql(qmu);
+            qcv.wait(ql, [&] { return prog_bands_drained >= prog_bands - 1 || drain_rc.load() != W2XC_OK; });
+        }
+        if (drain_rc.load()) return drain_rc.load();
+        if (p.flags_epoch[par] == 0x7FFFFFFFu) { memset(p.pin_flags[par], 0, p.flags_n[par] * sizeof(unsigned)); p.flags_epoch[par] = 0; }   // (the epoch comparison is signed: start over, nothing is in flight on this buffer)
+        pt->out = (float *)p.pin_band[par];
+        pt->out_stride_f = (long long)W;
+        pt->flags = p.pin_flags[par];
+        pt->epoch = ++p.flags_epoch[par];
+        return W2XC_OK;
+    };
+    hk.prog_launched = [&](int y0, int y1, int trows, int groups, int first) -> int {
+        if (trace && t_first_out < 0) t_first_out = ms_since(t0);
+        if (out_pinned) return W2XC_OK;
+        const int par = (int)(prog_bands & 1);
+        Chunk ch{y0, y1, -1};
+        ch.trows = trows; ch.groups = groups; ch.first = first;
+        ch.flags = p.pin_flags[par]; ch.epoch = p.flags_epoch[par]; ch.src = p.pin_band[par];
+        {
+            std::lock_guard<std::mutex> ql(qmu);
+            pending.push_back(ch);
+            prog_bands++;
+        }
+        qcv.notify_all();
         return W2XC_OK;
     };
 

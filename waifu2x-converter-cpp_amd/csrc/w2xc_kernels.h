@@ -45,6 +45,18 @@ struct W2xcConvDesc {
     // conv3x3_wino: 0 / 1 = the 2x2 output blocks start at row -wino_py of this launch's region, so that they sit on EVEN rows of the
     // layer's whole output whatever row the band starts at -- a pixel's arithmetic then does not depend on the banding.
     int wino_py;
+    // conv3x3_wino4 with out_terms = 9 and prog_cnt != NULL (PROG): the launch finishes the fused one-plane last layer itself, in row order -- g_out = that
+    // layer's output rows (g_h x g_w, row stride g_out_rs floats), output row y reads the partial tap rows y + g_off .. y + g_off + 2 of `out`, g_bias its
+    // bias; prog_cnt = w2xc_wino4_prog_counters() job counters (zeroed by the launcher on the stream).
+    unsigned *prog_cnt;
+    float *g_out;
+    const float *g_bias;
+    long long g_out_rs;
+    int g_h, g_w, g_off;
+    // ... with prog_flags != NULL (page-locked HOST memory, one word per job = (tile row, group of 8 tile columns), w2xc_wino4_prog_jobs()) every finished job
+    // stores prog_epoch there at system scope behind its output rows: the host pipeline's drainer ships rows while the launch is still running
+    unsigned *prog_flags;
+    unsigned prog_epoch;
 };
 
 enum W2xcKernelKind {
@@ -92,6 +104,10 @@ void w2xc_first2_wino4_pack(const float *w, float *dst);
 hipError_t w2xc_launch_first2_wino4(const W2xcConvDesc &d, hipStream_t stream);
 // d.out_terms = 9: the one-plane LAST layer in conv3x3_wino4's epilogue; d.w7pk = w2xc_wino4_pack_last image, `out` = partial tap planes
 // G[64-plane block][tap][y][x] (out_ts / out_gs / out_rs), finished by W2XC_K_LAST_GATHER with halves = cout / 64
+bool w2xc_wino4_prog_supported(int cin, int cout);
+size_t w2xc_wino4_prog_counters(int out_w, int out_h, int wino_py);
+// the job grid of such a launch: tile rows (16 rows each, the first one starting wino_py rows above the region) x groups of 8 tile columns (256 pixels)
+void w2xc_wino4_prog_jobs(int out_w, int out_h, int wino_py, int *tile_rows, int *groups);
 size_t w2xc_wino4_pack_last_floats(int cin);
 void w2xc_wino4_pack_last(int cin, const float *w, float *dst);
 

@@ -369,6 +369,8 @@ int w2xc_model_trim(w2xc_model *m)
         if (p.d_out) { hipFree(p.d_out); p.d_out = nullptr; p.d_out_bytes = 0; }
         if (p.pin_in) { hipHostFree(p.pin_in); p.pin_in = nullptr; p.in_slot_bytes = 0; }
         if (p.pin_out) { hipHostFree(p.pin_out); p.pin_out = nullptr; p.out_slot_bytes = 0; }
+        for (int i = 0; i < 2; i++)
+            if (p.pin_band[i]) { hipHostFree(p.pin_band[i]); p.pin_band[i] = nullptr; p.band_bytes[i] = 0; }
     }
     hipSetDevice(prev);
     return W2XC_OK;
@@ -466,6 +468,8 @@ const char *w2xc_layer_kernel_name(const w2xc_model *m, int layer, const w2xc_op
     if (!m || layer < 0 || layer >= (int)m->layers.size()) return "";
     const w2xc_opts o = resolve_opts(opts);
     const W2xcKernelKind k = layer_kind(m, layer, o);
+    // (what the DEVICE entry points launch: conv3x3_wino4 PROG finishes the last layer itself there only on request; the host entry points always use it)
+    if (k == W2XC_K_LAST_GATHER && gather_in_producer(m, o) && o.fusion == W2XC_FUSION_PROG) return "(in_previous_layer)";
     if (k == W2XC_K_MFMA) {
         const int midv = layer_mid_variant(m, layer, o);
         if (midv != MID_MFMA) return midv == MID_WINO4 ? "conv3x3_wino4" : "conv3x3_wino";

@@ -143,6 +143,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
         memset(&first_d, 0, sizeof first_d);
         int src_h = vh, src_w = w;
         int Tprev = vy0;   // first plane row held by the buffer layer k reads (the source view for k = 1)
+        bool gathered_in_producer = false;
         for (int k = 1; k <= n; k++) {
             if (o.verbose & 1) std::cout << "Iteration #" << k << "..." << std::endl;   // convertRoutine.cpp:67
             const HostLayer &hl = m->layers[k - 1];
@@ -211,10 +212,58 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 }
                 if (T > 0 && d.out_terms >= 1 && d.out_terms <= 3) { d.out_rs = (long long)d.out_w * split_grp; d.out_ps = split_grp; }
                 if (d.out_terms == 9) {   // G[half][tap][y][x]
-                    d.out_rs = d.out_w; d.out_ps = 1;
-                    d.out_gs = (long long)d.out_h * d.out_w;
+                    // (where the producing launch finishes the last layer itself -- conv3x3_wino4 PROG --, rows start on 128-byte lines: a tile's 32-pixel row
+                    //  segment of a tap plane is then exactly ONE line, written whole, and a gather job never pulls a line into its XCD's L2 that holds
+                    //  columns of a tile it does not depend on -- with rows of out_w floats such a line, cached before its last columns were written, was
+                    //  served stale to the neighbouring job later: intermittent mismatches on small planes)
+                    d.out_rs = (T == 0 && gather_in_producer(m, o)) ? ((d.out_w + 31) & ~31) : d.out_w; d.out_ps = 1;
+                    d.out_gs = (long long)d.out_h * d.out_rs;
                     d.out_ts = 9 * d.out_gs;
                     d.halves = fused_halves(T, hl.nout);   // (fp32: conv3x3_wino4 writes planar partial planes G[64-plane block][tap][y][x]: its epilogue sums the four plane tiles of a block on chip)
+                }
+            }
+            // fp32, the launch of layer n - 1 FINISHES the fused one-plane last layer itself, rows completing top to bottom while it runs (conv3x3_wino4 PROG):
+            //   * host pipeline (hk->prog_begin): ONE launch of layer n - 1, no gather launch, no chunking -- its gather jobs write the band's output rows
+            //     straight into page-locked host memory and flag them; the drainer ships rows while the launch is still running (the 0.15-0.25 ms that
+            //     three chunked launches of the persistent kernel cost, the six gather launches and their events are gone: DESIGN 7);
+            //   * device entry points: only on request (w2xc_opts.fusion = W2XC_FUSION_PROG) -- with planes resident nothing waits for rows, and the launch
+            //     is 0.2 ms slower than layer n - 1 + its gather launch (the row-ordered walk, the write-through tap planes).
+            // Bit-identical to the gather launch either way (same sum, same order).
+            if (T == 0 && k == n - 1 && kind == W2XC_K_MFMA && d.out_terms == 9 && last_kind == W2XC_K_LAST_GATHER && last_direct && !all_out && d.in_ps == 1 &&
+                gather_in_producer(m, o) && w >= 4 && (long long)d.out_h * d.out_rs * 4 < (1ll << 32) && ((hk && hk->prog_begin) || (!hk && o.fusion == W2XC_FUSION_PROG))) {
+                int trows = 0, groups = 0;
+                w2xc_wino4_prog_jobs(d.out_w, d.out_h, d.wino_py, &trows, &groups);
+                BandHooks::ProgTail pt;
+                pt.out = d_out + (size_t)(y0 - ra) * out_stride_f;
+                pt.out_stride_f = (long long)out_stride_f;
+                if (hk) {
+                    pt.out = nullptr;
+                    int rc = hk->prog_begin(y0, y1, trows, groups, &pt);
+                    if (rc) return rc;
+                }
+                if (pt.out) {
+                    const size_t nc = w2xc_wino4_prog_counters(d.out_w, d.out_h, d.wino_py);
+                    if (c->prog_cnt_n < nc) {
+                        if (c->prog_cnt) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->prog_cnt)); c->prog_cnt = nullptr; c->prog_cnt_n = 0; }
+                        HIP_TRY(hipMalloc((void **)&c->prog_cnt, nc * sizeof(unsigned)));
+                        c->prog_cnt_n = nc;
+                    }
+                    d.prog_cnt = c->prog_cnt;
+                    d.g_out = pt.out;
+                    d.g_out_rs = pt.out_stride_f;
+                    d.g_h = y1 - y0;
+                    d.g_w = w;
+                    d.g_off = y0 - 1 - Tk;   // rows of this launch's region above the last layer's first input row
+                    d.g_bias = c->layers[n - 1].bias;
+                    d.prog_flags = pt.flags;
+                    d.prog_epoch = pt.epoch;
+                    if (hk && hk->prefetch && y1 < rb) { int rc = hk->prefetch(y1, std::min(rb, y1 + band)); if (rc) return rc; }
+                    int rc = launch_layer(c, m, k - 1, kind, d, st, o);
+                    if (rc) return rc;
+                    // job (tile row jr, group jg) holds the output rows [16 jr - first, 16 jr - first + 16) (clipped to the band) x columns [256 jg, 256 jg + 256)
+                    if (hk && hk->prog_launched) { rc = hk->prog_launched(y0, y1, trows, groups, d.wino_py + d.g_off); if (rc) return rc; }
+                    gathered_in_producer = true;
+                    break;
                 }
             }
             // 16-bit modes, host pipeline: the last layer lives in layer n-1's epilogue + a 0.2 ms gather, too short to hide the
@@ -359,6 +408,7 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 src_h = d.out_h; src_w = d.out_w;
                 continue;
             }
+            if (k == n && gathered_in_producer) break;   // (conv3x3_wino4 PROG finished this layer inside the previous launch; the host pipeline follows its job flags)
             const bool chunked = hk && k == n && direct_out && hk->out_chunk_rows > 0 && d.out_h > std::max(hk->out_chunk_min, 8) &&
                                  (kind == W2XC_K_LAST || kind == W2XC_K_LAST_GATHER || kind == W2XC_K_DIRECT);
             if (chunked) {

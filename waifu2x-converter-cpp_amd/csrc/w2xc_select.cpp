@@ -37,6 +37,17 @@ W2xcKernelKind layer_kind(const w2xc_model *m, int l, const w2xc_opts &o)
 static bool fusion_first_on(const w2xc_opts &o) { return o.fusion != W2XC_FUSION_OFF && o.fusion != W2XC_FUSION_LAST; }
 static bool fusion_last_on(const w2xc_opts &o) { return o.fusion != W2XC_FUSION_OFF && o.fusion != W2XC_FUSION_FIRST; }
 
+// fp32, last layer fused (fuse_last_fp32): does the producing launch also FINISH it (conv3x3_wino4 PROG: the partial tap planes are summed by the workgroup
+// whose arrival completes a 16-row x 256-column job, rows complete top to bottom while the launch runs), or does a conv3x3_last_gather launch follow
+// (rounds 4 / 5; w2xc_opts.fusion = W2XC_FUSION_GATHER_LAUNCH, and the shapes PROG has no instantiation for)?  The two are bit-identical.
+bool gather_in_producer(const w2xc_model *m, const w2xc_opts &o)
+{
+    const int n = (int)m->layers.size();
+    if (!fuse_last_fp32(m, o) || o.fusion == W2XC_FUSION_GATHER_LAUNCH) return false;
+    if (!w2xc_wino4_prog_supported(m->layers[n - 2].nin, m->layers[n - 2].nout)) return false;
+    return planar_between(m, n - 3, o);   // (the PROG instantiations read planar planes)
+}
+
 // 16-bit modes: layers 1 (ONE plane -> 32) and 2 (32 -> {32,64,128}) run as one kernel (conv3x3_first2_split) when
 // layer 2 is an ordinary split mid layer.  w2xc_opts.fusion = W2XC_FUSION_OFF / _LAST disables.
 bool fuse_first(const w2xc_model *m, const w2xc_opts &o)
@@ -196,7 +207,7 @@ void RowPlan::ws_need(const w2xc_model *m, int rows, size_t need[2]) const
         const bool fused = ot == 9;   // partial G planes of the fused last layer
         const size_t bpe = (ot >= 1 && ot <= 3) ? 2 * (size_t)ot : 4;   // bytes per activation element of layer k's output
         const size_t px_bytes = fused ? (size_t)fused_halves(T, m->layers[k - 1].nout) * 9 * 4 : m->layers[k - 1].nout * bpe;
-        const size_t wk_mem = planar_between(m, k - 1, o) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows start on 128-byte lines
+        const size_t wk_mem = (planar_between(m, k - 1, o) || (fused && T == 0 && gather_in_producer(m, o))) ? ((wk + 31) & ~(size_t)31) : wk;   // planar rows (and the tap planes a PROG launch gathers itself) start on 128-byte lines
         need[(k - 1) & 1] = std::max(need[(k - 1) & 1], hk * wk_mem * px_bytes);
     }
 }
@@ -227,7 +238,7 @@ int plan_rows(const w2xc_model *m, const w2xc_opts &o_in, int w, int vh, int vy0
             return fail(W2XC_ERR_PLANES, "Error : Model-filter : \nnumber of input planes mismatch.\n%d,%d", m->layers[l - 1].nout, m->layers[l].nin);
     P.T = split_terms(P.o);
     if (P.o.precision != W2XC_PRECISION_FP32 && P.T == 0) return fail(W2XC_ERR_ARG, "unknown precision %d", P.o.precision);
-    if (P.o.fusion < W2XC_FUSION_AUTO || P.o.fusion > W2XC_FUSION_LAST) return fail(W2XC_ERR_ARG, "unknown w2xc_opts.fusion %d", P.o.fusion);
+    if (P.o.fusion < W2XC_FUSION_AUTO || P.o.fusion > W2XC_FUSION_PROG) return fail(W2XC_ERR_ARG, "unknown w2xc_opts.fusion %d", P.o.fusion);
     if (P.T > 0)
         for (int l = 0; l < n; l++)
             if (layer_kind(m, l, P.o) == W2XC_K_DIRECT)

@@ -110,9 +110,60 @@ static constexpr __host__ __device__ int w4p_dd_of(int xi) { return 6 * ((xi % 1
 
 }   // namespace
 
-template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false>
+// 16-byte / 4-byte global stores written THROUGH to memory at device scope (sc1): what another workgroup of this launch, on any XCD, reads after
+// the writer has drained them (s_waitcnt vmcnt(0)) and counted its arrival -- no release fence, the XCD's L2 keeps no dirty line (PROG below)
+static __device__ __forceinline__ void store16_sc1(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+static __device__ __forceinline__ void store4_sc1(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+// ... and at SYSTEM scope (sc0 sc1): the gather jobs' output rows, which the host pipeline's drainer reads from page-locked host memory as soon as the job's flag
+// says so.  Plain stores stayed in the XCD's L2 until the launch ended -- fine-grained host memory is only promised at system-scope synchronisation -- and the
+// flag (a system-scope store) arrived long before the rows it announced (measured: stale rows in a third of the frame).
+static __device__ __forceinline__ void store16_sys(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+static __device__ __forceinline__ void store4_sys(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+
+// a batch of N 16-byte sc1 loads (scalar base b[k] + one 32-bit lane offset) issued back to back, and the "+v" pins that keep every destination
+// behind the batch's wait (an asm load's destination counts as written at the end of its statement: nothing may read or move it before the wait)
+template <int K, int N>
+static __device__ __forceinline__ void load16_sc1_batch(f32x4 (&t)[N], unsigned voff, const char *const (&b)[N])
+{
+    if constexpr (K < N) {
+        // (s_nop 4: the scalar base may just have been restored from a spill lane -- a VALU write of an SGPR needs five wait states before a VMEM instruction
+        //  reads it as its address, and the hazard recogniser does not look inside an asm statement: without it the load went off a stale base and faulted)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(t[K]) : "v"(voff), "s"(b[K]) : "memory");
+        load16_sc1_batch<K + 1, N>(t, voff, b);
+    }
+}
+template <int K, int N>
+static __device__ __forceinline__ void pin_batch(f32x4 (&t)[N])
+{
+    if constexpr (K < N) {
+        asm volatile("" : "+v"(t[K]));
+        pin_batch<K + 1, N>(t);
+    }
+}
+template <int K, int N>
+static __device__ __forceinline__ void sum_batch(f32x4 &v, const f32x4 (&t)[N])
+{
+    if constexpr (K < N) {
+        v += t[K];
+        sum_batch<K + 1, N>(v, t);
+    }
+}
+
+// PROG (with FUSE7): the launch FINISHES the fused last layer itself and finishes it in row order, so that the output plane completes top to bottom
+// while the launch is still running (round 6; convertRoutine.cpp:143-161's stitch no longer waits for the layer's end):
+//   * schedule: XCD k owns the tile columns [(k tiles_x + phi) / 8, ((k + 1) tiles_x + phi) / 8) of tile row r, phi = r & 7, and walks them row by row --
+//     all eight XCDs work on the same tile rows at the same time (the strip walk above finishes the lower 40 % of every strip only at the very end);
+//     the band edges move by at most one tile from row to row and eight rows hold exactly tiles_x tiles of every XCD: equal shares for any width;
+//   * every item writes its partial tap planes through to memory (sc1) and, one item later -- when the stores have long drained --, counts its
+//     arrival on the GATHER JOBS it feeds: job (r, g) = the last layer's outputs whose first tap row lies in tile row r and whose columns lie in the
+//     tile group [8 g, 8 g + 8); it needs the tiles of rows r, r + 1 and columns 8 g .. 8 g + 8 (two more tap rows below, two more columns to the right);
+//   * the workgroup whose arrival completes a job runs it: conv3x3_last_gather's sum (taps outer, 64-plane blocks inner: bit-identical), bias,
+//     LeakyReLU, stores into the output plane; with d.prog_flags the job's completion is published to the host (system scope) for the drainer.
+//   No workgroup ever waits for another one (no spinning, no residency assumption): arrivals are returning atomics, the last one does the work.
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false, bool PROG = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tiles_x, int nitems)
 {
+    static_assert(!PROG || FUSE7, "PROG finishes the fused last layer");
     constexpr int ROWS = 16;
     constexpr int NST = CIN / 4;                            // stages (4-channel slices) per item
     constexpr int NOB = COUT / 64;                          // 64-plane blocks
@@ -125,8 +176,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     constexpr unsigned BIAS_BASE = SPARE_BASE + V_BYTES;
     static_assert(CIN % 16 == 0 && COUT % 64 == 0 && NST % 4 == 0 && NST >= 8, "planes");
     constexpr int STRIP = 16;
+    constexpr int GW = 8;                                   // PROG: tiles per gather-job column group
+    constexpr unsigned TRIG_BASE = BIAS_BASE + COUT * 4;    // PROG: one LDS word, the jobs this workgroup's arrivals completed
     const int tiles_y = nitems / (NOB * tiles_x);
+    const int pxcd = blockIdx.x & 7;
+    auto band_lo = [&](int k, int r) { return (k * tiles_x + (r & 7)) >> 3; };   // PROG: first tile column of XCD k in tile row r
     auto tile_coords = [&](int pt_, int &ty_, int &tx_) {     // strips of 16 tiles, row by row inside a strip (the next round of an XCD is the tile row below)
+        if constexpr (PROG) {   // pt_ = index into THIS XCD's band, row by row; a period of eight rows holds exactly tiles_x of its tiles
+            const int p8 = pt_ / tiles_x;
+            int rem = pt_ - p8 * tiles_x, j = 0, lo = band_lo(pxcd, 0), wd = band_lo(pxcd + 1, 0) - lo;
+            while (rem >= wd && j < 7) {
+                rem -= wd;
+                j++;
+                lo = band_lo(pxcd, j);
+                wd = band_lo(pxcd + 1, j) - lo;
+            }
+            ty_ = 8 * p8 + j;
+            tx_ = lo + rem;
+            return;
+        }
         const int per_strip = STRIP * tiles_y;
         int sidx = pt_ / per_strip;
         const int nfull = tiles_x / STRIP;
@@ -152,14 +220,23 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const int cq = nitems >> 3, cr = nitems & 7;
-    const int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-    const int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
+    int chunk_begin = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    int chunk_end = chunk_begin + cq + (xcd < cr ? 1 : 0);
+    if constexpr (PROG) {   // items = indices into this XCD's own band (tile_coords above)
+        int nloc = (tiles_y >> 3) * tiles_x;
+        for (int j = 0; j < (tiles_y & 7); j++) nloc += band_lo(xcd + 1, j) - band_lo(xcd, j);
+        chunk_begin = 0;
+        chunk_end = nloc * NOB;
+    }
     const int item0 = chunk_begin + (blockIdx.x >> 3);
     if (item0 >= chunk_end) return;
     const int nmy = (chunk_end - item0 + per - 1) / per;
     auto item_of = [&](int n) { return item0 + (n < nmy ? n : nmy - 1) * per; };
 
     for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
+    if constexpr (PROG) {
+        if (threadIdx.x < 4) lds[TRIG_BASE / 4 + threadIdx.x] = 0.0f;   // no job to run, no ticket in hand
+    }
 
     // ---- raw tile transfers: chunk ci = piece * 64 + lane -> (channel kk, row R, quad q); wave w < DW sends pieces w, w + DW, ... ----
     const long long cs4 = d.in_cs * 4, rs4 = d.in_rs * 4;     // bytes
@@ -287,6 +364,145 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
     // that are idle then -- and take them back behind it.  Nothing else of a transform touches LDS between its raw reads and its V writes: round 4's
     // earlier forms parked the intermediates of EVERY transform in the V ring (row-pass waves -> column-pass waves), and that traffic alone cost 0.7
     // of layer 6's 6.7 ms (timing-only ablation, profiles/r4_sweeps.log 8).
+    // ---- PROG: arrivals and gather jobs (see the comment above the kernel) ----
+    const int ngroups = (tiles_x + GW - 1) / GW;
+    // lane l < 4 of an item at tile (r, tx): the job it feeds -- (r - (l & 1), tx / 8 - (l >> 1)); the left neighbour group only from the group's first column
+    auto job_of_lane = [&](int item, int l, int &jr, int &jg) {
+        int r, tx;
+        tile_coords(item / NOB, r, tx);
+        jr = r - (l & 1);
+        jg = tx / GW - (l >> 1);
+        return l < 4 && jr >= 0 && ((l >> 1) == 0 || ((tx & (GW - 1)) == 0 && tx > 0));
+    };
+    auto job_target = [&](int jr, int jg) {   // arrivals that complete job (jr, jg)
+        const int rows = jr + 1 < tiles_y ? 2 : 1;
+        const int c1 = (jg + 1) * GW + 1;
+        return NOB * rows * ((c1 < tiles_x ? c1 : tiles_x) - jg * GW);
+    };
+    // The counter buffer (zeroed by the launcher in front of every launch): [0, njobs) arrivals per job | [njobs, 2 njobs) the READY QUEUE, slot -> job + 1 |
+    // head, tail.  The workgroup whose arrival completes a job only PUSHES it (tail++, then the slot); any workgroup that sees head < tail at an item
+    // boundary draws a ticket (head++) and runs the job of that slot at its next boundary.  (Letting the last arriver run the job itself fed back on
+    // itself: the slowest workgroup of a neighbourhood is the last arriver every round, got all its jobs -- +20 % on the launch, measured.)
+    // All of it is done by wave 7, which issues neither tap-plane stores nor transfers: the compiler's wait for a returned value is vmcnt(0), and in a
+    // storing wave that waits for the stores just issued as well.
+    const int njobs = tiles_y * ngroups;
+    unsigned *const q_slots = d.prog_cnt + njobs, *const q_head = d.prog_cnt + 2 * njobs, *const q_tail = q_head + 1;
+    unsigned *const lds_action = reinterpret_cast<unsigned *>(ldsb + TRIG_BASE), *const lds_ticket = lds_action + 1;   // job + 1 to run now | slot + 1 drawn, not yet run
+    constexpr int CW = 7;   // the control wave
+    // control wave, early in the epilogue: count the arrival of `item` (whose tap planes have drained) on its jobs -- every lane keeps what its job's
+    // counter held before --, and look at the queue: the slot of the ticket in hand, or head and tail
+    auto prog_early = [&](int item, unsigned &tick, unsigned &q0, unsigned &q1) {
+        tick = 0xFFFFFFFFu;
+        if (item >= 0) {
+            int jr, jg;
+            if (job_of_lane(item, lane_o(), jr, jg)) tick = __hip_atomic_fetch_add(d.prog_cnt + (jr * ngroups + jg), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned t = *lds_ticket;
+        q0 = __hip_atomic_load(t ? q_slots + (t - 1) : q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q1 = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // control wave, late in the epilogue: push the jobs the arrivals completed; take the job of the ticket in hand if its slot has been filled, or draw a
+    // ticket if a ready job has none -> the LDS words every wave reads behind the next barrier
+    auto prog_late = [&](int item, unsigned tick, unsigned q0, unsigned q1) {
+        if (item >= 0) {
+            int jr, jg;
+            const bool valid = job_of_lane(item, lane_o(), jr, jg);
+            if (valid && tick == (unsigned)(job_target(jr, jg) - 1)) {   // this arrival was the job's last one
+                const unsigned slot = __hip_atomic_fetch_add(q_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q_slots + slot, (unsigned)(jr * ngroups + jg) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        unsigned t = *lds_ticket, action = 0;
+        if (t) {
+            if (q0) { action = q0; t = 0; }
+        } else if ((int)(q1 - q0) > 0) {
+            unsigned h = 0;
+            if (lane_o() == 0) h = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+            t = h < (unsigned)njobs ? h + 1 : 0;   // (a ticket past the last job: every job has been drawn)
+        }
+        if (lane_o() == 0) { *lds_action = action; *lds_ticket = t; }
+    };
+    // every wave: the last layer's outputs of job (jr, jg): out(y, x) = leaky(bias + sum over taps and 64-plane blocks of G[block][tap][y + off + ty][x + tx]),
+    // summed in conv3x3_last_gather_x4's order (taps outer, blocks inner) -- the two paths are bit-identical.  The other workgroups' tap planes were written
+    // through (sc1) and drained before their arrivals were counted: they are read with sc1 loads (past this CU's L1, which may hold lines an earlier job
+    // read next to them), no fence.  Two pixel quads per thread = 36 (NOB = 2) 16-byte loads in flight, issued as one batch and waited for once: left to
+    // the compiler -- which schedules for registers in this kernel -- every load was followed by its own vmcnt(0) (365 us per job instead of ~5).
+    auto prog_job = [&](int jr, int jg) {
+        const int y_first = ROWS * jr - d.wino_py - d.g_off;
+        const int y_lo = y_first > 0 ? y_first : 0, y_hi = y_first + ROWS < d.g_h ? y_first + ROWS : d.g_h;
+        const int x_lo = jg * GW * 32, x_hi = (jg + 1) * GW * 32 < d.g_w ? (jg + 1) * GW * 32 : d.g_w;
+        const int nq = x_hi > x_lo ? (x_hi - x_lo + 3) >> 2 : 0;
+        const int total = y_hi > y_lo ? (y_hi - y_lo) * nq : 0;   // (jobs of tile rows / groups outside the last layer's plane: nothing to sum, still reported)
+        const float b = d.g_bias[0];
+        const int tid = wave * 64 + lane_o();
+        // scalar bases of the 9 NOB (tap, block) planes, the tap's row and column shift included
+        const char *gb[9 * NOB];
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+            for (int hf = 0; hf < NOB; hf++)
+            {   // (readfirstlane: an "s" operand of an asm statement must be PROVABLY uniform, or the compiler hands it a VGPR pair and the assembler refuses)
+                const unsigned long long a = (unsigned long long)(d.out + hf * d.out_ts + tap * d.out_gs + (long long)(tap / 3) * d.out_rs + (tap % 3));
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+                gb[tap * NOB + hf] = reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+            }
+        for (int q0 = tid; q0 < total; q0 += 1024) {
+            f32x4 t0[9 * NOB], t1[9 * NOB];
+            // quad q -> (row, first column); a ragged last quad of a row is loaded from the row's last four columns instead (still inside the row: it has two
+            // more) and picked apart below.  32-bit byte offsets inside a tap plane (the launcher checks the plane's size).
+            const bool on0 = true, on1 = q0 + 512 < total;
+            const int qa = q0, qb = on1 ? q0 + 512 : q0;
+            const int ya = qa / nq, yb = qb / nq;
+            const int yy0 = y_lo + ya, yy1 = y_lo + yb, xx0 = x_lo + (qa - ya * nq) * 4, xx1 = x_lo + (qb - yb * nq) * 4;
+            const bool whole0 = xx0 + 4 <= d.g_w, whole1 = xx1 + 4 <= d.g_w;
+            const unsigned voff0 = (unsigned)(((long long)(yy0 + d.g_off) * d.out_rs + (whole0 ? xx0 : d.g_w - 4)) * 4);
+            const unsigned voff1 = (unsigned)(((long long)(yy1 + d.g_off) * d.out_rs + (whole1 ? xx1 : d.g_w - 4)) * 4);
+            load16_sc1_batch<0, 9 * NOB>(t0, voff0, gb);
+            if (on1) load16_sc1_batch<0, 9 * NOB>(t1, voff1, gb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the batch
+            pin_batch<0, 9 * NOB>(t0);
+            pin_batch<0, 9 * NOB>(t1);
+            auto finish = [&](bool on, const f32x4 (&t)[9 * NOB], int yy, int xx, bool whole) {
+                if (!on) return;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                sum_batch<0, 9 * NOB>(v, t);
+                float *oq = d.g_out + (long long)yy * d.g_out_rs + xx;
+                if (whole) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = leaky(v[e] + b);
+                    store16_sys(oq, o);
+                } else {
+                    // the row's last 1..3 pixels: the batch held columns g_w - 4 .. g_w - 1 (+ the tap's shift); pixel xx + e sits at index xx + e - (g_w - 4)
+                    const int sh = xx - (d.g_w - 4);
+                    for (int e = 0; xx + e < d.g_w; e++) {
+                        const int idx = sh + e;
+                        const float ve = idx == 0 ? v[0] : idx == 1 ? v[1] : idx == 2 ? v[2] : v[3];
+                        store4_sys(oq + e, leaky(ve + b));
+                    }
+                }
+            };
+            finish(on0, t0, yy0, xx0, whole0);
+            finish(on1, t1, yy1, xx1, whole1);
+        }
+        // d.prog_flags (host pipeline): the job's rows are on their way to host memory (g_out is page-locked host memory there: uncached on this side, the
+        // stores are posted PCIe writes): every wave waits for its stores to have left, then ONE system-scope store publishes the job to the drainer thread,
+        // behind the data on the same link
+        if (d.prog_flags) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wave == 0 && lane_o() == 0) __hip_atomic_store(d.prog_flags + (jr * ngroups + jg), d.prog_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // every wave: run the job the control wave has named
+    auto prog_run = [&]() {
+        const unsigned action = (unsigned)__builtin_amdgcn_readfirstlane((int)*lds_action);
+        if (action) prog_job((int)(action - 1) / ngroups, (int)(action - 1) % ngroups);
+        return action;
+    };
+
     float dd[36];
     auto raw_read = [&](const char *src, auto I_) {          // patch row i
         constexpr int i = decltype(I_)::value;
@@ -580,6 +796,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                 for (int e = 0; e < 4; e++) a7[e] = w7[e * 64];
             }
             char *red = ldsb + V_BASE + V_BYTES;   // (V slot 1: idle until the next item's first stage writes V of its second)
+            unsigned tick = 0xFFFFFFFFu, pq0 = 0, pq1 = 0;   // PROG, control wave: what the job counters of the PREVIOUS item's arrivals held; the queue
+            (void)tick; (void)pq0; (void)pq1;
             // [pt][tap][128 pixels] floats (18 KiB)
             // The row transform A^T M of every column, all four rows at once (10 operations per column and plane; two passes over row PAIRS recompute
             // the four sums and differences: 14): the six accumulators of a (column, plane) are dead behind it, their registers hold its four results.
@@ -596,6 +814,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                     tm[2][j][e] = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
                     tm[3][j][e] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m5));
                 }
+            // PROG: the PREVIOUS item's tap planes (and every transfer but the youngest) have long landed: this wait is all but free here, and makes
+            // that item's arrival countable behind the first barrier below
+            if constexpr (PROG) W2XC_WAIT_VMCNT(0);
 #pragma unroll
             for (int rp = 0; rp < 2; rp++) {
 #pragma unroll
@@ -634,6 +855,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
+                        if constexpr (PROG) {
+                            // (every wave has drained the previous item's stores in front of this barrier) its arrival, counted by wave 0; the counters'
+                            // answers are looked at three row steps further down
+                            if (i == 0 && wave == CW) prog_early(n > 0 ? item_of(n - 1) : -1, tick, pq0, pq1);
+                            if (i == 3 && wave == CW) prog_late(n > 0 ? item_of(n - 1) : -1, tick, pq0, pq1);
+                        }
                         {
                             const int tid = wave * 64 + lane_e;
                             if (tid < 288) {
@@ -644,7 +871,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
                                 for (int q = 1; q < 4; q++) sum += *reinterpret_cast<const f32x4 *>(red + ((q * 9 + tap) * 128 + p) * 4);   // (fixed order: reproducible)
                                 if (gy >= 0 && gy < d.out_h && gx < d.out_w) {
                                     float *g = d.out + (long long)ob * d.out_ts + (long long)tap * d.out_gs + (long long)gy * d.out_rs + gx;
-                                    if (gx + 3 < d.out_w) *reinterpret_cast<f32x4u *>(g) = sum;   // (dword-aligned: rows of out_w floats)
+                                    if constexpr (PROG) {   // written through: read by the gather job of whichever workgroup arrives last
+                                        if (gx + 3 < d.out_w) store16_sc1(g, sum);
+                                        else {
+#pragma unroll
+                                            for (int e = 0; e < 3; e++)
+                                                if (gx + e < d.out_w) store4_sc1(g + e, sum[e]);
+                                        }
+                                    } else if (gx + 3 < d.out_w) *reinterpret_cast<f32x4u *>(g) = sum;   // (dword-aligned: rows of out_w floats)
                                     else {
 #pragma unroll
                                         for (int e = 0; e < 3; e++)
@@ -676,6 +910,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
             }
             __builtin_amdgcn_s_setprio(0);
             W4_STAMP(stamp++);
+            // PROG: the gather jobs the previous item's arrivals completed (the LDS word was written in front of the epilogue's last barrier)
+            if constexpr (PROG) prog_run();
         }
         // the transforms in flight back into registers; the barrier: the next stage's U transfers land on the parking area
         if constexpr (PH != 0) unpark();
@@ -684,6 +920,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         asm volatile("" ::: "memory");
     }
     W2XC_WAIT_VMCNT(0);   // drain the speculative transfers before the LDS is released
+    if constexpr (PROG) {
+        // the workgroup's LAST item: its tap planes have drained (the wait above, every wave), its arrival is counted and what it completed is pushed; then
+        // the workgroup works the queue off -- this once with every latency exposed -- until it holds no ticket and sees no ready job without one.  Jobs pushed
+        // later are drawn by workgroups still running or by their pusher's own pass through here; a ticket whose slot is still empty is waited for (the slot
+        // is filled by a workgroup that is running and waits for nobody).
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bool first = true;
+        for (;;) {
+            if (wave == CW) {
+                unsigned tick, q0, q1;
+                prog_early(first ? item_of(nmy - 1) : -1, tick, q0, q1);
+                prog_late(first ? item_of(nmy - 1) : -1, tick, q0, q1);
+                unsigned t = *lds_ticket;
+                if (*lds_action == 0 && t) {   // a ticket in hand: wait for its slot
+                    unsigned q = 0;
+                    while ((q = __hip_atomic_load(q_slots + (t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
+                    if (lane_o() == 0) { *lds_action = q; *lds_ticket = 0; }
+                }
+            }
+            const bool was_first = first;
+            first = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned ran = prog_run();
+            __builtin_amdgcn_s_barrier();   // (the control wave rewrites the words)
+            asm volatile("" ::: "memory");
+            // (the first pass looked at the queue BEFORE it pushed what this workgroup's last arrival completed: the pass that ends the loop is one that
+            //  has seen the queue after every push of this workgroup -- or the last pusher of the launch would leave with its job still in the queue)
+            if (!ran && !was_first) break;
+        }
+    }
     };
 #ifdef W4_ONE_PH   // timing-only (tools/ubench): every wave runs the copy of phase W4_ONE_PH -- wrong results, the same work per stage, a quarter of the hot code
     run(std::integral_constant<int, W4_ONE_PH>{});
@@ -703,14 +972,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
 #ifndef W2XC_WINO4_PART
 #define W2XC_WINO4_PART -1   // one translation unit with everything (tools/ubench)
 #endif
-template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false>
+template <int CIN, int COUT, bool OUT_PLANAR, bool IN_NHWC = false, bool FUSE7 = false, bool PROG = false>
 static hipError_t launch_wino4(const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + (d.wino_py & 3) + 15) / 16;
     const int nitems = tiles_x * tiles_y * (COUT / 64);
-    constexpr size_t lds_bytes = 3 * (size_t)(11 * 1024) + 2 * (size_t)(36 * 1024) + 3 * (size_t)(18 * 1024) + COUT * 4;   // raw + U + V + bias
+    constexpr size_t lds_bytes = 3 * (size_t)(11 * 1024) + 2 * (size_t)(36 * 1024) + 3 * (size_t)(18 * 1024) + COUT * 4 + (PROG ? 16 : 0);   // raw + U + V + bias (+ the job word)
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_wino4<CIN, COUT, OUT_PLANAR, IN_NHWC, FUSE7>;
+    if constexpr (PROG) {
+        // the job counters start at zero in EVERY launch (a memset node in front of the kernel, on its stream)
+        if (!d.prog_cnt || !d.g_out || !d.g_bias || d.g_w < 4 || (long long)d.out_h * d.out_rs * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit offsets inside a tap plane, whole quads)
+        hipError_t em = hipMemsetAsync(d.prog_cnt, 0, w2xc_wino4_prog_counters(d.out_w, d.out_h, d.wino_py) * sizeof(unsigned), stream);
+        if (em != hipSuccess) return em;
+    }
+    auto kern = conv3x3_wino4<CIN, COUT, OUT_PLANAR, IN_NHWC, FUSE7, PROG>;
     static std::atomic<unsigned long long> attr_done{0};   // function attributes are per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -756,8 +1031,19 @@ hipError_t w2xc_launch_wino4_fused(const W2xcConvDesc &d, hipStream_t stream);
 hipError_t w2xc_launch_wino4_fused(const W2xcConvDesc &d, hipStream_t stream)
 {
 #ifdef W4P_SINGLE
+    if (d.prog_cnt) return d.cin == 128 && d.cout == 128 && d.in_ps == 1 ? launch_wino4<128, 128, true, false, true, true>(d, stream) : hipErrorInvalidValue;
     return d.cin == 128 && d.cout == 128 && d.in_ps == 1 ? launch_wino4<128, 128, true, false, true>(d, stream) : hipErrorInvalidValue;
 #else
+    if (d.prog_cnt) {   // the launch finishes the last layer itself (PROG); planar 64 / 128-plane inputs (the 7-layer models' layer n - 1)
+        if (d.in_ps != 1) return hipErrorInvalidValue;
+        switch (d.cin * 1000 + d.cout) {
+        case 64064:  return launch_wino4<64, 64, true, false, true, true>(d, stream);
+        case 64128:  return launch_wino4<64, 128, true, false, true, true>(d, stream);
+        case 128064: return launch_wino4<128, 64, true, false, true, true>(d, stream);
+        case 128128: return launch_wino4<128, 128, true, false, true, true>(d, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (d.cin == 32 && d.in_ps == 32 && d.in_cs == 1)
         return d.cout == 64 ? launch_wino4<32, 64, true, true, true>(d, stream) : d.cout == 128 ? launch_wino4<32, 128, true, true, true>(d, stream) : hipErrorInvalidValue;
     switch (d.cin * 1000 + d.cout) {
@@ -788,6 +1074,19 @@ void w2xc_wino4_pack_last(int cin, const float *w, float *dst)
 bool w2xc_wino4_supported(int cin, int cout)
 {
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+}
+// PROG: the fused launch that finishes the last layer itself exists for planar 64 / 128-plane inputs
+bool w2xc_wino4_prog_supported(int cin, int cout) { return (cin == 64 || cin == 128) && (cout == 64 || cout == 128); }
+// ... and its control words: per job (tile row, group of 8 tile columns of the launch's region) an arrival counter and a queue slot, + head and tail
+void w2xc_wino4_prog_jobs(int out_w, int out_h, int wino_py, int *tile_rows, int *groups)
+{
+    *tile_rows = (out_h + (wino_py & 3) + 15) / 16;
+    *groups = ((out_w + 31) / 32 + 7) / 8;
+}
+size_t w2xc_wino4_prog_counters(int out_w, int out_h, int wino_py)
+{
+    const int tiles_x = (out_w + 31) / 32, tiles_y = (out_h + (wino_py & 3) + 15) / 16;
+    return 2 * (size_t)tiles_y * ((tiles_x + 7) / 8) + 2;   // arrivals per job | the ready queue | head, tail
 }
 
 // wpk[64-plane block ob][stage s (4 channels)][xi / 4][plane tile pt][lane = 16 k + o][xi % 4] = U_xi[plane 64 ob + 16 pt + o][channel 4 s + k], xi = xi_of(i, j),
