@@ -228,10 +228,23 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         chunk_begin = 0;
         chunk_end = nloc * NOB;
     }
-    const int item0 = chunk_begin + (blockIdx.x >> 3);
-    if (item0 >= chunk_end) return;
-    const int nmy = (chunk_end - item0 + per - 1) / per;
-    auto item_of = [&](int n) { return item0 + (n < nmy ? n : nmy - 1) * per; };
+#ifndef W4_PAIR
+#define W4_PAIR 0   // (experiment, profiles/r6_sweeps.log 3) 1: a workgroup runs BOTH 64-plane items of a tile back to back instead of the two items side by side on two workgroups
+#endif
+    int item0 = chunk_begin + (blockIdx.x >> 3);
+    int nmy = (chunk_end - item0 + per - 1) / per;
+    if constexpr (W4_PAIR && NOB == 2 && !PROG) {
+        const int ntile = nitems >> 1, tq = ntile >> 3, tr = ntile & 7;
+        const int tb = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, te = tb + tq + (xcd < tr ? 1 : 0);
+        item0 = tb + (blockIdx.x >> 3);            // (a TILE index in this form)
+        if (item0 >= te) return;
+        nmy = 2 * ((te - item0 + per - 1) / per);
+    } else if (item0 >= chunk_end) return;
+    auto item_of = [&](int n) {
+        const int nn = n < nmy ? n : nmy - 1;
+        if constexpr (W4_PAIR && NOB == 2 && !PROG) return 2 * (item0 + (nn >> 1) * per) + (nn & 1);
+        else return item0 + nn * per;
+    };
 
     for (int c = threadIdx.x; c < COUT; c += 512) lds[BIAS_BASE / 4 + c] = d.bias[c];   // (visible after the prologue barrier)
     if constexpr (PROG) {
