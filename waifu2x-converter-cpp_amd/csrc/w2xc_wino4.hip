@@ -149,6 +149,95 @@ static __device__ __forceinline__ void sum_batch(f32x4 &v, const f32x4 (&t)[N])
     }
 }
 
+// One gather job of a PROG launch (below): the last layer's outputs of job (jr, jg) -- rows [16 jr - wino_py - g_off, + 16) x columns [256 jg, + 256) clipped to its
+// plane --: out(y, x) = leaky(bias + sum over taps and 64-plane blocks of G[block][tap][y + g_off + ty][x + tx]), summed in conv3x3_last_gather_x4's order (taps outer,
+// blocks inner: the two paths are bit-identical).  The other workgroups' tap planes were written through (sc1) and drained before their arrivals were counted: they
+// are read with sc1 loads (past this CU's L1), no fence.  Two pixel quads per thread = 36 (NOB = 2) 16-byte loads in flight, issued as one asm batch and waited for once:
+// left to the compiler -- which schedules for registers in this kernel -- every load was followed by its own vmcnt(0) (365 us per job instead of ~5).
+// A FUNCTION OF ITS OWN, never inlined: as a lambda inside the kernel this code cost layer 6 0.2 ms without ever running (profiles/r6_sweeps.log 1d) -- its scalar
+// state competed with the stage loop's for SGPRs and the epilogue came out differently; behind a call it has its own registers.
+struct W4ProgJob {
+    const float *G; long long ts, gs, rs;          // partial tap planes G[block][tap][y][x]: block / tap-plane / row strides in floats
+    float *out; long long out_rs;                  // the last layer's output rows
+    const float *bias;
+    unsigned *flags; unsigned epoch;               // host pipeline: one word per job, written behind the rows (NULL: none)
+    int g_h, g_w, g_off, wino_py, ngroups;
+};
+template <int NOB>
+static __device__ __attribute__((noinline)) void w4_prog_job(W4ProgJob a, int jr, int jg)
+{
+    constexpr int ROWS = 16, GW = 8;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };   // (arguments of a device function arrive in VGPRs: everything wave-uniform is made provably so)
+    auto uni64 = [&](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32) | (unsigned)uni((int)(unsigned)v); };
+    jr = uni(jr); jg = uni(jg);
+    const int g_h = uni(a.g_h), g_w = uni(a.g_w), g_off = uni(a.g_off);
+    const long long rs = (long long)uni64((unsigned long long)a.rs), gs = (long long)uni64((unsigned long long)a.gs), ts = (long long)uni64((unsigned long long)a.ts);
+    const long long out_rs = (long long)uni64((unsigned long long)a.out_rs);
+    const float *G = reinterpret_cast<const float *>(uni64((unsigned long long)a.G));
+    float *outp = reinterpret_cast<float *>(uni64((unsigned long long)a.out));
+    const int tid = (int)threadIdx.x;
+    const int y_first = ROWS * jr - uni(a.wino_py) - g_off;
+    const int y_lo = y_first > 0 ? y_first : 0, y_hi = y_first + ROWS < g_h ? y_first + ROWS : g_h;
+    const int x_lo = jg * GW * 32, x_hi = (jg + 1) * GW * 32 < g_w ? (jg + 1) * GW * 32 : g_w;
+    const int nq = x_hi > x_lo ? (x_hi - x_lo + 3) >> 2 : 0;
+    const int total = y_hi > y_lo ? (y_hi - y_lo) * nq : 0;   // (jobs of tile rows / groups outside the last layer's plane: nothing to sum, still reported)
+    const float b = reinterpret_cast<const float *>(uni64((unsigned long long)a.bias))[0];
+    // scalar bases of the 9 NOB (tap, block) planes, the tap's row and column shift included
+    const char *gb[9 * NOB];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int hf = 0; hf < NOB; hf++) gb[tap * NOB + hf] = reinterpret_cast<const char *>(uni64((unsigned long long)(G + hf * ts + tap * gs + (long long)(tap / 3) * rs + (tap % 3))));
+    for (int q0 = tid; q0 < total; q0 += 1024) {
+        f32x4 t0[9 * NOB], t1[9 * NOB];
+        // quad q -> (row, first column); a ragged last quad of a row is loaded from the row's last four columns instead (still inside the row: it has two
+        // more) and picked apart below.  32-bit byte offsets inside a tap plane (the launcher checks the plane's size).
+        const bool on1 = q0 + 512 < total;
+        const int qa = q0, qb = on1 ? q0 + 512 : q0;
+        const int ya = qa / nq, yb = qb / nq;
+        const int yy0 = y_lo + ya, yy1 = y_lo + yb, xx0 = x_lo + (qa - ya * nq) * 4, xx1 = x_lo + (qb - yb * nq) * 4;
+        const bool whole0 = xx0 + 4 <= g_w, whole1 = xx1 + 4 <= g_w;
+        const unsigned voff0 = (unsigned)(((long long)(yy0 + g_off) * rs + (whole0 ? xx0 : g_w - 4)) * 4);
+        const unsigned voff1 = (unsigned)(((long long)(yy1 + g_off) * rs + (whole1 ? xx1 : g_w - 4)) * 4);
+        load16_sc1_batch<0, 9 * NOB>(t0, voff0, gb);
+        if (on1) load16_sc1_batch<0, 9 * NOB>(t1, voff1, gb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the batch
+        pin_batch<0, 9 * NOB>(t0);
+        pin_batch<0, 9 * NOB>(t1);
+        auto finish = [&](bool on, const f32x4 (&t)[9 * NOB], int yy, int xx, bool whole) {
+            if (!on) return;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            sum_batch<0, 9 * NOB>(v, t);
+            float *oq = outp + (long long)yy * out_rs + xx;
+            if (whole) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = leaky(v[e] + b);
+                store16_sys(oq, o);
+            } else {
+                // the row's last 1..3 pixels: the batch held columns g_w - 4 .. g_w - 1 (+ the tap's shift); pixel xx + e sits at index xx + e - (g_w - 4)
+                const int sh = xx - (g_w - 4);
+                for (int e = 0; xx + e < g_w; e++) {
+                    const int idx = sh + e;
+                    const float ve = idx == 0 ? v[0] : idx == 1 ? v[1] : idx == 2 ? v[2] : v[3];
+                    store4_sys(oq + e, leaky(ve + b));
+                }
+            }
+        };
+        finish(true, t0, yy0, xx0, whole0);
+        finish(on1, t1, yy1, xx1, whole1);
+    }
+    // flags (host pipeline): the job's rows are on their way to host memory (`out` is page-locked host memory there: the stores are posted PCIe writes, issued at
+    // system scope): every wave waits for its stores to have left, then ONE system-scope store publishes the job to the drainer thread, behind the data on the same link
+    unsigned *flags = reinterpret_cast<unsigned *>(uni64((unsigned long long)a.flags));
+    if (flags) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid == 0) __hip_atomic_store(flags + (jr * uni(a.ngroups) + jg), (unsigned)uni((int)a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // PROG (with FUSE7): the launch FINISHES the fused last layer itself and finishes it in row order, so that the output plane completes top to bottom
 // while the launch is still running (round 6; convertRoutine.cpp:143-161's stitch no longer waits for the layer's end):
 //   * schedule: XCD k owns the tile columns [(k tiles_x + phi) / 8, ((k + 1) tiles_x + phi) / 8) of tile row r, phi = r & 7, and walks them row by row --
@@ -436,83 +525,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino4(W2xcConvDesc d, int tile
         }
         if (lane_o() == 0) { *lds_action = action; *lds_ticket = t; }
     };
-    // every wave: the last layer's outputs of job (jr, jg): out(y, x) = leaky(bias + sum over taps and 64-plane blocks of G[block][tap][y + off + ty][x + tx]),
-    // summed in conv3x3_last_gather_x4's order (taps outer, blocks inner) -- the two paths are bit-identical.  The other workgroups' tap planes were written
-    // through (sc1) and drained before their arrivals were counted: they are read with sc1 loads (past this CU's L1, which may hold lines an earlier job
-    // read next to them), no fence.  Two pixel quads per thread = 36 (NOB = 2) 16-byte loads in flight, issued as one batch and waited for once: left to
-    // the compiler -- which schedules for registers in this kernel -- every load was followed by its own vmcnt(0) (365 us per job instead of ~5).
-    auto prog_job = [&](int jr, int jg) {
-        const int y_first = ROWS * jr - d.wino_py - d.g_off;
-        const int y_lo = y_first > 0 ? y_first : 0, y_hi = y_first + ROWS < d.g_h ? y_first + ROWS : d.g_h;
-        const int x_lo = jg * GW * 32, x_hi = (jg + 1) * GW * 32 < d.g_w ? (jg + 1) * GW * 32 : d.g_w;
-        const int nq = x_hi > x_lo ? (x_hi - x_lo + 3) >> 2 : 0;
-        const int total = y_hi > y_lo ? (y_hi - y_lo) * nq : 0;   // (jobs of tile rows / groups outside the last layer's plane: nothing to sum, still reported)
-        const float b = d.g_bias[0];
-        const int tid = wave * 64 + lane_o();
-        // scalar bases of the 9 NOB (tap, block) planes, the tap's row and column shift included
-        const char *gb[9 * NOB];
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++)
-#pragma unroll
-            for (int hf = 0; hf < NOB; hf++)
-            {   // (readfirstlane: an "s" operand of an asm statement must be PROVABLY uniform, or the compiler hands it a VGPR pair and the assembler refuses)
-                const unsigned long long a = (unsigned long long)(d.out + hf * d.out_ts + tap * d.out_gs + (long long)(tap / 3) * d.out_rs + (tap % 3));
-                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-                gb[tap * NOB + hf] = reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
-            }
-        for (int q0 = tid; q0 < total; q0 += 1024) {
-            f32x4 t0[9 * NOB], t1[9 * NOB];
-            // quad q -> (row, first column); a ragged last quad of a row is loaded from the row's last four columns instead (still inside the row: it has two
-            // more) and picked apart below.  32-bit byte offsets inside a tap plane (the launcher checks the plane's size).
-            const bool on0 = true, on1 = q0 + 512 < total;
-            const int qa = q0, qb = on1 ? q0 + 512 : q0;
-            const int ya = qa / nq, yb = qb / nq;
-            const int yy0 = y_lo + ya, yy1 = y_lo + yb, xx0 = x_lo + (qa - ya * nq) * 4, xx1 = x_lo + (qb - yb * nq) * 4;
-            const bool whole0 = xx0 + 4 <= d.g_w, whole1 = xx1 + 4 <= d.g_w;
-            const unsigned voff0 = (unsigned)(((long long)(yy0 + d.g_off) * d.out_rs + (whole0 ? xx0 : d.g_w - 4)) * 4);
-            const unsigned voff1 = (unsigned)(((long long)(yy1 + d.g_off) * d.out_rs + (whole1 ? xx1 : d.g_w - 4)) * 4);
-            load16_sc1_batch<0, 9 * NOB>(t0, voff0, gb);
-            if (on1) load16_sc1_batch<0, 9 * NOB>(t1, voff1, gb);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the batch
-            pin_batch<0, 9 * NOB>(t0);
-            pin_batch<0, 9 * NOB>(t1);
-            auto finish = [&](bool on, const f32x4 (&t)[9 * NOB], int yy, int xx, bool whole) {
-                if (!on) return;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                sum_batch<0, 9 * NOB>(v, t);
-                float *oq = d.g_out + (long long)yy * d.g_out_rs + xx;
-                if (whole) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = leaky(v[e] + b);
-                    store16_sys(oq, o);
-                } else {
-                    // the row's last 1..3 pixels: the batch held columns g_w - 4 .. g_w - 1 (+ the tap's shift); pixel xx + e sits at index xx + e - (g_w - 4)
-                    const int sh = xx - (d.g_w - 4);
-                    for (int e = 0; xx + e < d.g_w; e++) {
-                        const int idx = sh + e;
-                        const float ve = idx == 0 ? v[0] : idx == 1 ? v[1] : idx == 2 ? v[2] : v[3];
-                        store4_sys(oq + e, leaky(ve + b));
-                    }
-                }
-            };
-            finish(on0, t0, yy0, xx0, whole0);
-            finish(on1, t1, yy1, xx1, whole1);
-        }
-        // d.prog_flags (host pipeline): the job's rows are on their way to host memory (g_out is page-locked host memory there: uncached on this side, the
-        // stores are posted PCIe writes): every wave waits for its stores to have left, then ONE system-scope store publishes the job to the drainer thread,
-        // behind the data on the same link
-        if (d.prog_flags) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (wave == 0 && lane_o() == 0) __hip_atomic_store(d.prog_flags + (jr * ngroups + jg), d.prog_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    };
     // every wave: run the job the control wave has named
     auto prog_run = [&]() {
         const unsigned action = (unsigned)__builtin_amdgcn_readfirstlane((int)*lds_action);
-        if (action) prog_job((int)(action - 1) / ngroups, (int)(action - 1) % ngroups);
+        if (action) {
+            W4ProgJob a;
+            a.G = d.out; a.ts = d.out_ts; a.gs = d.out_gs; a.rs = d.out_rs;
+            a.out = d.g_out; a.out_rs = d.g_out_rs; a.bias = d.g_bias; a.flags = d.prog_flags; a.epoch = d.prog_epoch;
+            a.g_h = d.g_h; a.g_w = d.g_w; a.g_off = d.g_off; a.wino_py = d.wino_py; a.ngroups = ngroups;
+            w4_prog_job<NOB>(a, (int)(action - 1) / ngroups, (int)(action - 1) % ngroups);
+        }
         return action;
     };
 
