@@ -297,9 +297,10 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                 if (ch.slot < 0) {
                     // follow the job flags: tile rows complete top to bottom (roughly); every run of finished tile rows is stitched at once
                     const int R = ch.r1 - ch.r0;
-                    int jr = 0;
+                    int jr = 0, runs = 0;
                     long spins = 0;
                     bool launch_over = false;
+                    double t_first_seen = 0, t_last_seen = 0;
                     while (jr < ch.trows && drain_rc.load() == W2XC_OK) {
                         int ready = jr;
                         while (ready < ch.trows) {
@@ -325,6 +326,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                         }
                         std::atomic_thread_fence(std::memory_order_acquire);
                         const int a = std::max(0, 16 * jr - ch.first), b = std::min(R, 16 * ready - ch.first);
+                        const double t_seen = trace ? ms_since(t0) : 0.0;
                         if (b > a) {
                             try {
                                 w2xc_host::CopyPool::get().copy_rows((char *)out + (size_t)(ch.r0 + a) * out_stride, out_stride, ch.src + (size_t)a * out_row, out_row, out_row,
@@ -337,8 +339,15 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                                 drain_rc.store(W2XC_ERR_NOMEM);
                             }
                         }
+                        if (trace) {
+                            if (runs == 0) t_first_seen = t_seen;
+                            runs++;
+                            t_last_seen = t_seen;
+                        }
                         jr = ready;
                     }
+                    if (trace) fprintf(stderr, "[w2xc host] rows %d..%d finished by the launch of layer n-1 itself: %d tile rows stitched in %d runs, first seen %.3f ms, last seen %.3f ms, "
+                                               "stitched %.3f ms%s\n", ch.r0, ch.r1, ch.trows, runs, t_first_seen, t_last_seen, ms_since(t0), launch_over ? " (the launch was over before its last flags were seen)" : "");
                     {
                         std::lock_guard<std::mutex> ql(qmu);
                         prog_bands_drained++;
@@ -499,7 +508,8 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     rc = run_rows(m, c, p.d_in, w, svh << up, sy0 << up, W, ra, rb, p.d_out, W, p.s_compute, o, up, 1, 0, 0, &hk, H);
     const double t_enq = ms_since(t0);
     double t_comp = 0;
-    if (trace) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
+    // (not while a PROG band is being followed: the drainer polls hipStreamQuery on the same stream, and a synchronise in flight here holds it up until the launch ends)
+    if (trace && prog_bands == 0) { hipStreamSynchronize(p.s_compute); t_comp = ms_since(t0); }
     std::string err = g_last_error;
     finish_drainer();
     if (trace) fprintf(stderr, "[w2xc host] device %d (cpu node %d%s) rows %d..%d: input queued %.3f ms, first output chunk enqueued %.3f ms, enqueued %.3f ms, layers done %.3f ms, stitched %.3f ms (in %s, out %s, %d copy threads)\n",
