@@ -34,12 +34,12 @@ Extra objects on the JSON line:
                That layer runs a Winograd kernel (conv3x3_wino4, F(4x4,3x3): 36 instead of 144 multiplies per plane pair and
                4x4 block; conv3x3_wino, F(2x2,3x3): 16 instead of 36 per 2x2 block; all fp32).  `achieved` / `frac`
                are what the MFMA pipe really does: the FLOPs the kernel ISSUES (1/4 resp. 16/36 of the algorithmic ones) over time, against the peak -- always < 1, and
-               reproducible from profiles/r5_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
+               reproducible from profiles/r6_kernel_stats.csv.  The algorithmic rate (SURVEY 8d's FLOPs over the same
                time) is carried beside it as `algorithmic_tflops` / `algorithmic_speedup_vs_direct_roofline` (> 1 means
                faster than ANY direct convolution could be on this MFMA).  w2xc_opts.kernel = W2XC_KERNEL_MFMA runs
                conv3x3_mfma2, where executed = algorithmic.  A fused last layer is counted at its useful FLOPs (2 x 9 x Cin per pixel).
                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same command
-               (profiles/r5_roofline.json), only when that profile was taken from the kernel sources being run
+               (profiles/r6_roofline.json), only when that profile was taken from the kernel sources being run
                (hash check), else null.
   parity_patch_max_rel_err   one border and one interior 48x48 patch of the plane that was TIMED against the CPU oracle (the checker).
   cpu_baseline the CPU oracle (reference-faithful restatement; OpenCV is unavailable so the real binary cannot be

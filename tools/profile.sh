@@ -3,7 +3,7 @@
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2..: PMC counters, each in its
 # own run with --kernel-trace only (never combined with sys/hip/hsa tracing).
 # Results land in gpurun_out/prof_<tag>/ ; copy the summaries to profiles/ afterwards.
-TAG=${1:-r5}
+TAG=${1:-r6}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
