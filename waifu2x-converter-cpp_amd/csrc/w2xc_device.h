@@ -46,15 +46,16 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 // ---- LDS-DMA (global_load_lds_dwordx4) and counted waits ----------------------------------------
-// (s_nop 3 in front of every transfer: one state for the write of m0, and -- round 6 -- five in all behind a scalar base that the compiler has just restored
-//  from a spill lane with v_readlane: "VALU writes an SGPR -> VMEM reads it" needs 5 wait states and the hazard recogniser does not look into an asm
-//  statement; tools/check_sgpr_vmem_hazard.py found such pairs 4 states apart in the kernels of round 5, which had worked because the stale half of the
-//  base was the same value)
+// ("VALU writes an SGPR -> VMEM reads it" needs 5 wait states, and the hazard recogniser does not look into an asm statement: where the compiler had just
+//  restored a scalar base from a spill lane with v_readlane, the kernels of round 5 read it 4 states later -- tools/check_sgpr_vmem_hazard.py.  The transfers
+//  therefore read a COPY of the base made by the scalar ALU inside the statement: VALU -> SALU is interlocked by the hardware, SALU -> VMEM has no hazard, and
+//  the s_mov_b64 doubles as the one wait state the write of m0 needs -- no s_nop at all.  Round 6's first fix, s_nop 3 in every helper, cost every
+//  conv3x3_wino4 layer 1-1.5 %: r6_sweeps.log 6.)
 // m0 carries the wave-uniform LDS byte address of the transfer; it is compiler-reserved and this
 // kernel uses it for nothing else, so it is simply overwritten (clobber listed: hipcc only warns).
 static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_byte_addr)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, off"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :
                  : "v"(gptr), "s"(lds_byte_addr)
                  : "memory", "m0");
@@ -63,8 +64,9 @@ static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_
 template <int IMM>
 static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_byte_addr)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
-                 :
+    unsigned long long b;
+    asm volatile("s_mov_b32 m0, %3\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0 offset:%4"
+                 : "=&s"(b)
                  : "v"(voff), "s"(sbase), "s"(lds_byte_addr), "n"(IMM)
                  : "memory", "m0");
 }
@@ -72,8 +74,9 @@ static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned v
 template <unsigned LDS_IMM>
 static __device__ __forceinline__ void lds_dma16_si(const void *sbase, unsigned voff, unsigned lds_base)
 {
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
+    unsigned long long b;
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0"
+                 : "=&s"(b)
                  : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
                  : "memory", "m0", "scc");
 }
@@ -83,8 +86,9 @@ template <unsigned LDS_IMM, int GOFF>
 static __device__ __forceinline__ void lds_dma16_sio(const void *sbase, unsigned voff, unsigned lds_base)
 {
     static_assert(GOFF >= -4096 && GOFF <= 4095, "global_load_lds immediate offset");
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4"
-                 :
+    unsigned long long b;
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0 offset:%5"
+                 : "=&s"(b)
                  : "v"(voff), "s"(sbase), "s"(lds_base), "n"((int)LDS_IMM - GOFF), "n"(GOFF)
                  : "memory", "m0", "scc");
 }
