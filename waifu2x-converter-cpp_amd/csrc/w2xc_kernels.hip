@@ -386,30 +386,56 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     constexpr int K = 9 * CIN, S = (K + 1) / 2;
     constexpr int COUT = 32 * NBT;
     constexpr int TPS = 36;   // floats per pixel in the store-transpose tile: 32 planes + 4 pad (144-byte stride: conflict-free 16-byte writes)
-    __shared__ float lds[CIN * HH * HW];
-    __shared__ __attribute__((aligned(16))) float tps[4 * MB * 32 * TPS];   // per wave: its MB rows x 32 pixels x 32 planes
+    constexpr int PATCH = CIN * HH * HW, PL = (PATCH + 255) / 256;   // the tile's haloed source pixels; loads per thread
+    __shared__ float lds[PATCH];
+    __shared__ __attribute__((aligned(16))) float lbias[COUT];
+    constexpr int PLS = 68;   // planar out: floats per plane in the store-transpose tile, MB rows x 32 pixels + 4 pad (272-byte stride: conflict-free 16-byte writes)
+    __shared__ __attribute__((aligned(16))) float tps[PLANAR ? 4 * 32 * PLS : 4 * MB * 32 * TPS];   // per wave: its MB rows x 32 pixels x 32 planes
 
     // a workgroup walks FIRST_TPW consecutive tiles (a write-bound kernel of 32 791 four-wave workgroups was bound by their turnover)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 5, i = lane & 31;
     const int tile_base = xcd_remap(blockIdx.x, (ntiles + FIRST_TPW - 1) / FIRST_TPW) * FIRST_TPW;
+    // The layer's weights live in REGISTERS for the workgroup's lifetime (NBT x S <= 56 values per lane), the biases in LDS.  Round 6: loaded inside the
+    // plane-block loop, the compiler gave all S of them ONE register -- fourteen L2 round trips per plane block, each behind s_waitcnt vmcnt(0) (which also
+    // waited for the block's stores), and the patch fill was a loop of one load + vmcnt(0) per pass: 3 -> 128 on 2048 x 2048 ran 0.93 ms = 2.3 TB/s of
+    // writes where the same store stream alone reaches 5.5 (tools/ubench/planar_store.hip -- the stores' shape was never the limit).
+    float bw[NBT][S];
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+        for (int s = 0; s < S; s++) bw[nb][s] = d.wpk[(nb * S + s) * 64 + lane];
+    for (int idx = threadIdx.x; idx < COUT; idx += 256) lbias[idx] = d.bias[idx];
+
+    // the patch of one tile: PL loads per thread, all in flight at once (copyMakeBorder REPLICATE and INTER_NEAREST 2x folded into the addresses)
+    auto patch_load = [&](int tile, float (&v)[PL]) {
+        const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+        const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+#pragma unroll
+        for (int t = 0; t < PL; t++) {
+            const int idx = min(threadIdx.x + 256 * t, PATCH - 1);
+            const int c = idx / (HH * HW), p = idx - c * (HH * HW);
+            const int py = p / HW, px = p - py * HW;
+            const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;
+            const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;
+            v[t] = d.in[(long long)c * d.in_cs + (long long)gy * d.in_rs + (long long)gx * d.in_ps];
+        }
+    };
+    float pv[PL];
+    if (tile_base < ntiles) patch_load(tile_base, pv);
+
   for (int it = 0; it < FIRST_TPW; it++) {
     const int tile = tile_base + it;
     if (tile >= ntiles) break;                       // (workgroup-uniform)
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
     if (it) __syncthreads();                         // the previous tile's patch reads are done
-
-    for (int idx = threadIdx.x; idx < CIN * HH * HW; idx += 256) {
-        const int c = idx / (HH * HW), p = idx - c * (HH * HW);
-        const int py = p / HW, px = p - py * HW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;      // copyMakeBorder REPLICATE
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;      // (+ INTER_NEAREST 2x when in_shift = 1)
-        lds[idx] = d.in[(long long)c * d.in_cs + (long long)gy * d.in_rs + (long long)gx * d.in_ps];
-    }
+#pragma unroll
+    for (int t = 0; t < PL; t++)
+        if (threadIdx.x + 256 * t < PATCH) lds[threadIdx.x + 256 * t] = pv[t];
     __syncthreads();
 
-    const int kk = lane >> 5, i = lane & 31;
     float a[MB][S];
 #pragma unroll
     for (int s = 0; s < S; s++) {
@@ -420,18 +446,75 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) a[mb][s] = lds[(wave * MB + mb) * HW + i + off];
     }
+    // the next tile's patch is fetched under this tile's arithmetic and stores
+    if (it + 1 < FIRST_TPW && tile + 1 < ntiles) patch_load(tile + 1, pv);
 
-    // Operands swapped (weights = MFMA A, pixels = B): the accumulator tile is [plane][pixel], a lane owns pixel ox0 + i and
-    // per register quad q the 4 consecutive planes 32*nb + 8q + 4kk .. +3 -> one 16-byte (fp32) / 8-byte (bf16) store per
-    // quad instead of 4 scattered dwords; the accumulators start at the bias.
-#pragma unroll 1
-    for (int nb = 0; nb < NBT; nb++) {
-        float b[S];
+    if constexpr (PLANAR) {
+        // planar out (the layout conv3x3_wino4 reads).  Pixels = MFMA A, weights = B: the accumulator tile is [pixel][plane], a lane owns plane 32 nb + i and per
+        // register quad q the 4 CONSECUTIVE PIXELS 8q + 4kk .. +3 of a row.  The wave's MB rows x 32 pixels x 32 planes change owner through LDS (own region,
+        // no workgroup barrier) and leave as 16-byte stores, 8 lanes = the 128-byte line of one (plane, row): 8 store instructions per plane block where the
+        // dword form of rounds 3-5 (a half-wave = one line) issued 32 -- at ~28 cycles of the CU's address path per wave instruction those were the kernel's
+        // time once the weight loads were out of the way (0.52 ms; stores alone in that shape: tools/ubench/planar_store.hip).
+        float *tw = tps + wave * (32 * PLS);
+        const bool vec_ok = ((d.out_rs | d.out_cs) & 3) == 0 && d.out_rs >= ((d.out_w + 3) & ~3) && ((size_t)d.out & 15) == 0;   // (launch-uniform)
 #pragma unroll
-        for (int s = 0; s < S; s++) b[s] = d.wpk[(nb * S + s) * 64 + lane];
+        for (int nb = 0; nb < NBT; nb++) {
+            const float bv = lbias[nb * 32 + i];
+            f32x16 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mb][r] = bv;
+#pragma unroll
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][s], bw[nb][s], acc[mb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = leaky(acc[mb][4 * q + e]);
+                    *reinterpret_cast<f32x4 *>(tw + i * PLS + mb * 32 + 8 * q + 4 * kk) = v;
+                }
+            // (16-byte stores want rows and planes on 16-byte boundaries and room for a row's last quad: the engine's workspaces have both -- rows of
+            //  roundup32(w) floats; the quad's columns beyond out_w hold finite values nobody reads.  A caller's plane of any stride: dword stores.)
+            // lane = (pixel quad j, row mb, plane pl0 of a group of four); instruction n of a plane block covers planes 32 nb + 4 n + pl0
+            const int j = lane & 7, mb = (lane >> 3) % MB, pl0 = (lane >> 3) / MB;
+            static_assert(MB == 2, "lane map of the planar stores");
+            const float *tr = tw + pl0 * PLS + mb * 32 + 4 * j;
+            const int y = oy0 + wave * MB + mb, x = ox0 + 4 * j;
+            float *ob = d.out + ((long long)pl0 * d.out_cs + (long long)y * d.out_rs + x);   // + a wave-uniform plane offset per instruction
+            if (vec_ok) {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + n * 4 * PLS);
+                    if (y < d.out_h && x < d.out_w) *reinterpret_cast<f32x4 *>(ob + (long long)(nb * 32 + n * 4) * d.out_cs) = v;
+                }
+            } else {
+#pragma unroll 1
+                for (int n = 0; n < 8; n++) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + n * 4 * PLS);
+                    float *op = ob + (long long)(nb * 32 + n * 4) * d.out_cs;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (y < d.out_h && x + e < d.out_w) op[e] = v[e];
+                }
+            }
+        }
+        continue;   // (next tile)
+    }
+
+    // NHWC out.  Operands swapped (weights = MFMA A, pixels = B): the accumulator tile is [plane][pixel], a lane owns pixel ox0 + i and
+    // per register quad q the 4 consecutive planes 32*nb + 8q + 4kk .. +3 -> one 16-byte store per quad instead of 4 scattered dwords;
+    // the accumulators start at the bias.
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++) {
         f32x4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(d.bias + nb * 32 + 8 * q + 4 * kk);
+        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(lbias + nb * 32 + 8 * q + 4 * kk);
         f32x16 acc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
@@ -441,27 +524,11 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
         for (int s = 0; s < S; s++)
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[mb][s], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[nb][s], a[mb][s], acc[mb], 0, 0, 0);
         // Stores: a lane holds 4 x 4 consecutive planes of ONE pixel, so direct stores write 32-byte pieces of 32 different cache lines per
         // instruction -- 3.4-3.6 TB/s where a pure write stream reaches 6.9 (tools/ubench/hbm_streams.py).  The wave's MB x 32 pixels x 32
         // planes go through LDS instead (own region, no workgroup barrier) and leave as whole lines: 8 consecutive lanes = one pixel's
         // 128 bytes, 64 lanes = 8 pixels (1 KiB contiguous when COUT = 32).
-        if constexpr (PLANAR) {
-            // planar out (the layout conv3x3_wino4p reads): the 32 lanes of a half own 32 consecutive pixels of a row, so a plain dword store per
-            // (row, plane) already writes one whole 128-byte line per half-wave -- no transpose
-#pragma unroll
-            for (int mb = 0; mb < MB; mb++) {
-                const int y = oy0 + wave * MB + mb, x = ox0 + i;
-                if (y < d.out_h && x < d.out_w) {
-                    float *op = d.out + (long long)(nb * 32 + 4 * kk) * d.out_cs + (long long)y * d.out_rs + x;
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) op[(long long)(8 * q + e) * d.out_cs] = leaky(acc[mb][4 * q + e]);
-                }
-            }
-            continue;
-        }
         float *tw = tps + wave * (MB * 32 * TPS);
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
