@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     constexpr int COUT = 32 * NBT;
     constexpr int TPS = 36;   // floats per pixel in the store-transpose tile: 32 planes + 4 pad (144-byte stride: conflict-free 16-byte writes)
     constexpr int PATCH = CIN * HH * HW, PL = (PATCH + 255) / 256;   // the tile's haloed source pixels; loads per thread
-    __shared__ float lds[PATCH];
+    __shared__ float lds2[2][PATCH];   // the tile's patch, double-buffered: the next tile's is written while this one's stores are still in flight
     __shared__ __attribute__((aligned(16))) float lbias[COUT];
     constexpr int PLS = 68;   // planar out: floats per plane in the store-transpose tile, MB rows x 32 pixels + 4 pad (272-byte stride: conflict-free 16-byte writes)
     __shared__ __attribute__((aligned(16))) float tps[PLANAR ? 4 * 32 * PLS : 4 * MB * 32 * TPS];   // per wave: its MB rows x 32 pixels x 32 planes
@@ -424,17 +424,29 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
     };
     float pv[PL];
     if (tile_base < ntiles) patch_load(tile_base, pv);
+    // (register VALUES from here on: an empty asm statement "uses" every weight, so the waits for their loads stand here and not -- conservatively,
+    //  in every pass -- inside the tile loop)
+#pragma unroll
+    for (int nb = 0; nb < NBT; nb++)
+#pragma unroll
+        for (int s = 0; s < S; s++) asm volatile("" : "+v"(bw[nb][s]));
+    auto patch_to_lds = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < PL; t++)
+            if (threadIdx.x + 256 * t < PATCH) lds2[buf][threadIdx.x + 256 * t] = pv[t];
+    };
+    if (tile_base < ntiles) patch_to_lds(0);
 
   for (int it = 0; it < FIRST_TPW; it++) {
     const int tile = tile_base + it;
     if (tile >= ntiles) break;                       // (workgroup-uniform)
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
-    if (it) __syncthreads();                         // the previous tile's patch reads are done
-#pragma unroll
-    for (int t = 0; t < PL; t++)
-        if (threadIdx.x + 256 * t < PATCH) lds[threadIdx.x + 256 * t] = pv[t];
+    // ONE barrier per tile: this tile's patch (written behind the previous tile's first plane block, below) is complete, and every wave has read
+    // the patch of the tile before that, whose buffer the next write reuses
     __syncthreads();
+    const float *lds = lds2[it & 1];
+    const bool have_next = it + 1 < FIRST_TPW && tile + 1 < ntiles;
 
     float a[MB][S];
 #pragma unroll
@@ -446,8 +458,11 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) a[mb][s] = lds[(wave * MB + mb) * HW + i + off];
     }
-    // the next tile's patch is fetched under this tile's arithmetic and stores
-    if (it + 1 < FIRST_TPW && tile + 1 < ntiles) patch_load(tile + 1, pv);
+    // The next tile's patch is fetched under plane block 0's MFMAs and goes to LDS IN FRONT of that block's stores: vmcnt counts in order, so a wait
+    // for these loads also waits for every store issued before them -- here the previous tile's, a whole tile old; at the tile's end it would be
+    // this tile's own 32 stores, just issued (the compiler cannot count stores behind the edge tests and waits for all of them: measured, the
+    // workgroup then runs store-acknowledge to store-acknowledge).
+    if (have_next) patch_load(tile + 1, pv);
 
     if constexpr (PLANAR) {
         // planar out (the layout conv3x3_wino4 reads).  Pixels = MFMA A, weights = B: the accumulator tile is [pixel][plane], a lane owns plane 32 nb + i and per
@@ -470,6 +485,7 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][s], bw[nb][s], acc[mb], 0, 0, 0);
+            if (nb == 0 && have_next) patch_to_lds((it + 1) & 1);
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -525,6 +541,7 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[nb][s], a[mb][s], acc[mb], 0, 0, 0);
+        if (nb == 0 && have_next) patch_to_lds((it + 1) & 1);
         // Stores: a lane holds 4 x 4 consecutive planes of ONE pixel, so direct stores write 32-byte pieces of 32 different cache lines per
         // instruction -- 3.4-3.6 TB/s where a pure write stream reaches 6.9 (tools/ubench/hbm_streams.py).  The wave's MB x 32 pixels x 32
         // planes go through LDS instead (own region, no workgroup barrier) and leave as whole lines: 8 consecutive lanes = one pixel's
@@ -564,6 +581,9 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
 //   Then out[p][o] = leaky(bias[o] + sum_tap G[p + tap][tap*COUT + o]) via LDS.
 //   Workgroup = 4 waves, tile = ROWS x 32 output pixels.
 // ------------------------------------------------------------------------------------------------
+#ifndef LAST_TPW
+#define LAST_TPW 4
+#endif
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x, int ntiles)
 {
@@ -574,13 +594,12 @@ __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x,
     constexpr int S4 = CIN / 16;
     __shared__ float G[NBLK * 16 * GS];
 
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kk = lane >> 4, i = lane & 15;
 
+    // the layer's weights once per workgroup, which walks LAST_TPW consecutive tiles (round 6: one tile per workgroup re-read the 16 KiB image per tile,
+    // and a wave's pixel blocks ran load -> wait -> 64 MFMAs one after the other: 3.9 TB/s of reads on 128 -> 3)
     float b[S4][4][NB16];
 #pragma unroll
     for (int s4 = 0; s4 < S4; s4++)
@@ -589,50 +608,85 @@ __global__ void __launch_bounds__(256) conv3x3_last(W2xcConvDesc d, int tiles_x,
 #pragma unroll
             for (int nb = 0; nb < NB16; nb++) b[s4][j][nb] = d.wpk[((s4 * 4 + j) * NB16 + nb) * 64 + lane];
 
-    for (int blk = wave; blk < NBLK; blk += 4) {
+    // the 16 channels-of-four of pixel block `blk` of tile `tile` (clamped: the haloed tile's pixels outside the plane repeat the edge)
+    auto blk_load = [&](int tile, int blk, f32x4 (&v)[S4]) {
+        const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
         int q = blk * 16 + i;
         q = q < NPIX ? q : NPIX - 1;
         const int py = q / HW, px = q - py * HW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1);
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1);
-        f32x4 av[S4];
+        const int gy = clampi(tile_y * ROWS + py + d.off_y, 0, d.in_h - 1);
+        const int gx = clampi(tile_x * 32 + px + d.off_x, 0, d.in_w - 1);
         const f32x4 *src = reinterpret_cast<const f32x4 *>(d.in + (long long)gy * d.in_rs + (long long)gx * CIN) + kk;
 #pragma unroll
-        for (int s4 = 0; s4 < S4; s4++) av[s4] = src[s4 * 4];
-        f32x4 acc[NB16];
+        for (int s4 = 0; s4 < S4; s4++) v[s4] = src[s4 * 4];
+    };
+
+    float bo[COUT];
 #pragma unroll
-        for (int nb = 0; nb < NB16; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < COUT; o++) bo[o] = d.bias[o];
+    const int tile_base = xcd_remap(blockIdx.x, (ntiles + LAST_TPW - 1) / LAST_TPW) * LAST_TPW;
+    f32x4 av[S4];
+    if (tile_base < ntiles) blk_load(tile_base, wave, av);
+    // (register VALUES from here on: left pending, the weights' waits sit INSIDE the loop -- s_waitcnt vmcnt(7) behind the eight loads of the next
+    //  block, i.e. a wait for the first of those -- in every pass)
 #pragma unroll
-        for (int s4 = 0; s4 < S4; s4++)
+    for (int s4 = 0; s4 < S4; s4++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int nb = 0; nb < NB16; nb++)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][j], b[s4][j][nb], acc[nb], 0, 0, 0);
-        // C/D map of 16x16 MFMA: column = lane&15 (n), row = 4*(lane>>4) + r (pixel in block)
+            for (int nb = 0; nb < NB16; nb++) asm volatile("" : "+v"(b[s4][j][nb]));
+    for (int it = 0; it < LAST_TPW; it++) {
+        const int tile = tile_base + it;
+        if (tile >= ntiles) break;                       // (workgroup-uniform)
+        const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+        const int oy0 = tile_y * ROWS, ox0 = tile_x * 32;
+        for (int blk = wave; blk < NBLK; blk += 4) {
+            // the next block's loads (this tile's, or the first of the next tile) fly under this block's MFMAs
+            f32x4 nv[S4];
+            const bool more = blk + 4 < NBLK;
+            const bool next_tile = !more && it + 1 < LAST_TPW && tile + 1 < ntiles;
+            if (more) blk_load(tile, blk + 4, nv);
+            else if (next_tile) blk_load(tile + 1, wave, nv);
+            f32x4 acc[NB16];
 #pragma unroll
-        for (int nb = 0; nb < NB16; nb++) {
-            const int n = nb * 16 + i;
-            if (n < N) {
+            for (int nb = 0; nb < NB16; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; r++) G[(blk * 16 + kk * 4 + r) * GS + n] = acc[nb][r];
+            for (int s4 = 0; s4 < S4; s4++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int nb = 0; nb < NB16; nb++)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][j], b[s4][j][nb], acc[nb], 0, 0, 0);
+            // C/D map of 16x16 MFMA: column = lane&15 (n), row = 4*(lane>>4) + r (pixel in block)
+#pragma unroll
+            for (int nb = 0; nb < NB16; nb++) {
+                const int n = nb * 16 + i;
+                if (n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) G[(blk * 16 + kk * 4 + r) * GS + n] = acc[nb][r];
+                }
+            }
+            if (more || next_tile) {
+#pragma unroll
+                for (int s4 = 0; s4 < S4; s4++) av[s4] = nv[s4];
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    for (int p = threadIdx.x; p < ROWS * 32; p += 256) {
-        const int py = p >> 5, px = p & 31;
-        const int y = oy0 + py, x = ox0 + px;
-        if (y >= d.out_h || x >= d.out_w) continue;
+        for (int p = threadIdx.x; p < ROWS * 32; p += 256) {
+            const int py = p >> 5, px = p & 31;
+            const int y = oy0 + py, x = ox0 + px;
+            if (y >= d.out_h || x >= d.out_w) continue;
 #pragma unroll
-        for (int o = 0; o < COUT; o++) {
-            float v = 0.0f;
+            for (int o = 0; o < COUT; o++) {
+                float v = 0.0f;
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++)
-                v += G[((py + tap / 3) * HW + px + tap % 3) * GS + tap * COUT + o];
-            d.out[(long long)o * d.out_cs + (long long)y * d.out_rs + (long long)x * d.out_ps] = leaky(v + d.bias[o]);
+                for (int tap = 0; tap < 9; tap++)
+                    v += G[((py + tap / 3) * HW + px + tap % 3) * GS + tap * COUT + o];
+                d.out[(long long)o * d.out_cs + (long long)y * d.out_rs + (long long)x * d.out_ps] = leaky(v + bo[o]);
+            }
         }
+        __syncthreads();                                 // (G is rewritten by the next tile)
     }
 }
 
@@ -784,6 +838,15 @@ static hipError_t launch_tiled8(KernelT kernel, const W2xcConvDesc &d, hipStream
 }
 
 template <typename KernelT>
+static hipError_t launch_last(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
+{
+    const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
+    const int ntiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(kernel, dim3((ntiles + LAST_TPW - 1) / LAST_TPW), dim3(256), 0, stream, d, tiles_x, ntiles);
+    return hipGetLastError();
+}
+
+template <typename KernelT>
 static hipError_t launch_first(KernelT kernel, const W2xcConvDesc &d, hipStream_t stream)
 {
     const int tiles_x = (d.out_w + 31) / 32, tiles_y = (d.out_h + 7) / 8;
@@ -845,12 +908,12 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         if (d.in_ps != d.cin || d.in_cs != 1) return hipErrorInvalidValue;
         const int key = d.cin * 1000 + d.cout;
         switch (key) {
-        case 32001:  return launch_tiled8(conv3x3_last<32, 1>, d, stream);
-        case 64001:  return launch_tiled8(conv3x3_last<64, 1>, d, stream);
-        case 128001: return launch_tiled8(conv3x3_last<128, 1>, d, stream);
-        case 32003:  return launch_tiled8(conv3x3_last<32, 3>, d, stream);
-        case 64003:  return launch_tiled8(conv3x3_last<64, 3>, d, stream);
-        case 128003: return launch_tiled8(conv3x3_last<128, 3>, d, stream);
+        case 32001:  return launch_last(conv3x3_last<32, 1>, d, stream);
+        case 64001:  return launch_last(conv3x3_last<64, 1>, d, stream);
+        case 128001: return launch_last(conv3x3_last<128, 1>, d, stream);
+        case 32003:  return launch_last(conv3x3_last<32, 3>, d, stream);
+        case 64003:  return launch_last(conv3x3_last<64, 3>, d, stream);
+        case 128003: return launch_last(conv3x3_last<128, 3>, d, stream);
         default: return hipErrorInvalidValue;
         }
     }
