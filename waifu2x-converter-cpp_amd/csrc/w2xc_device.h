@@ -60,6 +60,14 @@ static __device__ __forceinline__ void lds_dma16(const void *gptr, unsigned lds_
                  : "v"(gptr), "s"(lds_byte_addr)
                  : "memory", "m0");
 }
+// one dword per lane (lane l lands at lds_byte_addr + 4 l): a gather of single pixels straight into LDS, no data register
+static __device__ __forceinline__ void lds_dma4(const void *gptr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :
+                 : "v"(gptr), "s"(lds_byte_addr)
+                 : "memory", "m0");
+}
 // scalar base + 32-bit per-lane byte offset + immediate: no 64-bit VALU address per transfer
 template <int IMM>
 static __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_byte_addr)

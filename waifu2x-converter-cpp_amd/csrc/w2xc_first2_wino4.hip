@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_first2_wino4(W2xcConvDesc d, i
     // scalar base, the lane's 4 hi planes + row + pixel in a 32-bit byte offset (the launcher checks the range)
     const int pt_o = wave >> 1, ep = wave & 1;
     const int o0 = 16 * pt_o + 4 * hi + 2 * ep;
-    const float bias0 = d.bias[o0], bias1 = d.bias[o0 + 1];
+    float bias0 = d.bias[o0], bias1 = d.bias[o0 + 1];
+    // (register VALUES from here on: left pending, the compiler waits for these two loads at every use inside the tile loop -- s_waitcnt vmcnt(0) in front
+    //  of each of the O phase's eight stores, i.e. every store waited for the one before it to be acknowledged: round 6, found in the ISA)
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
     char *obase[2];
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) obase[pl] = reinterpret_cast<char *>(d.out + (long long)(16 * pt_o + 2 * ep + pl) * d.out_cs);
@@ -116,12 +119,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_first2_wino4(W2xcConvDesc d, i
         // ================= S: the 12 x 38 source pixels of the tile (clamped = replicate padding; >> in_shift = nearest 2x) =================
         {
             const int ys = ty * 8 - d.wino_py + d.off_y, xs = tx * 32 + d.off_x;
-            for (int idx = threadIdx.x; idx < 12 * SW; idx += 256) {
-                const int py = idx / SW, px = idx - py * SW;
-                const int gy = clampi(ys + py, 0, d.in_h - 1) >> d.in_shift;
-                const int gx = clampi(xs + px, 0, d.in_w - 1) >> d.in_shift;
-                lds[SRC_FLOATS + idx] = d.in[(long long)gy * d.in_rs + gx];
+            // LDS-DMA, one dword per lane, both passes in flight at once and no data register (as a loop of load / s_waitcnt vmcnt(0) / ds_write this phase
+            // paid two memory round trips one after the other)
+            constexpr int SP = (12 * SW + 255) / 256;
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+#pragma unroll
+            for (int t = 0; t < SP; t++) {
+                const int idx = (int)threadIdx.x + 256 * t;
+                if (idx < 12 * SW) {
+                    const int py = idx / SW, px = idx - py * SW;
+                    const int gy = clampi(ys + py, 0, d.in_h - 1) >> d.in_shift;
+                    const int gx = clampi(xs + px, 0, d.in_w - 1) >> d.in_shift;
+                    lds_dma4(d.in + ((long long)gy * d.in_rs + gx), lds0 + (SRC_FLOATS + 256 * t + 64 * wave) * 4);
+                }
             }
+            W2XC_WAIT_VMCNT(0);
         }
         __syncthreads();
         W4S_STAMP(1);
