@@ -471,7 +471,6 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
         // dword form of rounds 3-5 (a half-wave = one line) issued 32 -- at ~28 cycles of the CU's address path per wave instruction those were the kernel's
         // time once the weight loads were out of the way (0.52 ms; stores alone in that shape: tools/ubench/planar_store.hip).
         float *tw = tps + wave * (32 * PLS);
-        const bool vec_ok = ((d.out_rs | d.out_cs) & 3) == 0 && d.out_rs >= ((d.out_w + 3) & ~3) && ((size_t)d.out & 15) == 0;   // (launch-uniform)
 #pragma unroll
         for (int nb = 0; nb < NBT; nb++) {
             const float bv = lbias[nb * 32 + i];
@@ -496,28 +495,17 @@ __global__ void __launch_bounds__(256) conv3x3_first(W2xcConvDesc d, int tiles_x
                     *reinterpret_cast<f32x4 *>(tw + i * PLS + mb * 32 + 8 * q + 4 * kk) = v;
                 }
             // (16-byte stores want rows and planes on 16-byte boundaries and room for a row's last quad: the engine's workspaces have both -- rows of
-            //  roundup32(w) floats; the quad's columns beyond out_w hold finite values nobody reads.  A caller's plane of any stride: dword stores.)
+            //  roundup32(w) floats -- and the launcher refuses anything else; the quad's columns beyond out_w hold finite values nobody reads)
             // lane = (pixel quad j, row mb, plane pl0 of a group of four); instruction n of a plane block covers planes 32 nb + 4 n + pl0
             const int j = lane & 7, mb = (lane >> 3) % MB, pl0 = (lane >> 3) / MB;
             static_assert(MB == 2, "lane map of the planar stores");
             const float *tr = tw + pl0 * PLS + mb * 32 + 4 * j;
             const int y = oy0 + wave * MB + mb, x = ox0 + 4 * j;
             float *ob = d.out + ((long long)pl0 * d.out_cs + (long long)y * d.out_rs + x);   // + a wave-uniform plane offset per instruction
-            if (vec_ok) {
 #pragma unroll
-                for (int n = 0; n < 8; n++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + n * 4 * PLS);
-                    if (y < d.out_h && x < d.out_w) *reinterpret_cast<f32x4 *>(ob + (long long)(nb * 32 + n * 4) * d.out_cs) = v;
-                }
-            } else {
-#pragma unroll 1
-                for (int n = 0; n < 8; n++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + n * 4 * PLS);
-                    float *op = ob + (long long)(nb * 32 + n * 4) * d.out_cs;
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (y < d.out_h && x + e < d.out_w) op[e] = v[e];
-                }
+            for (int n = 0; n < 8; n++) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + n * 4 * PLS);
+                if (y < d.out_h && x < d.out_w) *reinterpret_cast<f32x4 *>(ob + (long long)(nb * 32 + n * 4) * d.out_cs) = v;
             }
         }
         continue;   // (next tile)
@@ -880,7 +868,8 @@ hipError_t w2xc_launch_conv(W2xcKernelKind kind, const W2xcConvDesc &d, hipStrea
         default: return hipErrorInvalidValue;
         }
     }
-    if (kind == W2XC_K_FIRST && d.out_ps == 1 && d.cout > 1) {   // planar out
+    if (kind == W2XC_K_FIRST && d.out_ps == 1 && d.cout > 1) {   // planar out: whole pixel quads (the engine's planar workspaces; Model::filter goes through NHWC)
+        if (((d.out_rs | d.out_cs) & 3) != 0 || d.out_rs < ((d.out_w + 3) & ~3) || (((size_t)d.out) & 15) != 0) return hipErrorInvalidValue;
         switch (d.cin * 1000 + d.cout) {
         case 1032: return launch_first(conv3x3_first<1, 1, true>, d, stream);
         case 1064: return launch_first(conv3x3_first<1, 2, true>, d, stream);

@@ -126,9 +126,11 @@ template <int K, int N>
 static __device__ __forceinline__ void load16_sc1_batch(f32x4 (&t)[N], unsigned voff, const char *const (&b)[N])
 {
     if constexpr (K < N) {
-        // (s_nop 4: the scalar base may just have been restored from a spill lane -- a VALU write of an SGPR needs five wait states before a VMEM instruction
-        //  reads it as its address, and the hazard recogniser does not look inside an asm statement: without it the load went off a stale base and faulted)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(t[K]) : "v"(voff), "s"(b[K]) : "memory");
+        // (the load reads a COPY of its scalar base made by the scalar ALU inside the statement: the base may just have been restored from a spill lane, and a VALU
+        //  write of an SGPR needs five wait states before a VMEM instruction reads it as its address -- the hazard recogniser does not look inside an asm statement,
+        //  and without protection the load went off a stale base and faulted; VALU -> SALU is interlocked, SALU -> VMEM needs nothing: w2xc_device.h)
+        unsigned long long bc;
+        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1 sc1" : "=v"(t[K]), "=&s"(bc) : "v"(voff), "s"(b[K]) : "memory");
         load16_sc1_batch<K + 1, N>(t, voff, b);
     }
 }
