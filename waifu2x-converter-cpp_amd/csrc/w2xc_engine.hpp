@@ -273,6 +273,9 @@ struct BandHooks {
     // layer 1 in row chunks while the band's input is still arriving: in_chunk(y0, y1) > 0 = output rows of layer 1 per chunk
     // (0: the band's rows are already staged / one launch); input_upto(v) = make the launch stream wait for view rows <= v
     std::function<int(int, int)> in_chunk;
+    // optional: rows of the chunk that starts at output row c0 of the launch's region (multiples of 8; <= 0 = in_chunk's value) -- the first chunks of a call
+    // are short, so that the first launch follows the first kilobytes of the upload and not its first 2 MiB slice
+    std::function<int(int)> in_chunk_at;
     std::function<int(int)> input_upto;
     std::function<int(int, int)> prefetch;               // layers 1..n-1 of the current band are enqueued; [y0, y1) = the NEXT band
     std::function<int(int, int)> output_ready;           // output rows [r0, r1) have been enqueued on the launch stream

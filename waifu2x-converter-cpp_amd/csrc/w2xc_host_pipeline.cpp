@@ -409,6 +409,13 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         if (overlap || uploaded >= std::min(band_src_end(y1), svh)) return 0;
         return std::max(8, ((in_chunk_rows << up) + 7) & ~7);
     };
+    // the call's first chunks are an eighth, a quarter, a half of a slice: the first launch starts ~30 us into the call instead of behind the first 2 MiB
+    // (pageable: staged by the copy threads first); later chunks are whole slices, every launch of the persistent kernel has a ramp
+    hk.in_chunk_at = [&](int c0) -> int {
+        const int full = std::max(8, ((in_chunk_rows << up) + 7) & ~7);
+        if (uploaded > 0 && c0 == 0) return 0;   // (a later band whose first rows were prefetched)
+        return c0 < full / 8 ? full / 8 : c0 < full / 8 + full / 4 ? full / 4 : c0 < full / 8 + full / 4 + full / 2 ? full / 2 : full;
+    };
     hk.input_upto = [&](int vlast) -> int {
         int r = upload_to((vlast >> up) + 1);
         if (r) return r;

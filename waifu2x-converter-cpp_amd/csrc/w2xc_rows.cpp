@@ -388,9 +388,11 @@ int run_rows(w2xc_model *m, DevCtx *c, const float *d_in, size_t in_stride_f, in
                 // the upload of rows [c0 + 2 + off_y ...] and layer 1 of the rows before them overlap: what stays exposed of the
                 // input side is the first slice and the last chunk, not upload + layer 1 back to back.  (Layers 1 + 2 in one launch: the same,
                 // two rows deeper; chunks of whole 8-row tiles keep the 4x4 blocks where the unchunked launch has them.)
-                for (int c0 = 0; c0 < d.out_h; c0 += in_chunk) {
+                for (int c0 = 0, step = in_chunk; c0 < d.out_h; c0 += step) {
+                    step = in_chunk;
+                    if (hk->in_chunk_at) { const int s_ = hk->in_chunk_at(c0); if (s_ > 0) step = std::max(8, s_ & ~7); }
                     W2xcConvDesc dd = d;
-                    dd.out_h = std::min(in_chunk, d.out_h - c0);
+                    dd.out_h = std::min(step, d.out_h - c0);
                     dd.out = d.out + (size_t)c0 * d.out_rs;
                     dd.off_y = d.off_y + c0;
                     // last view row this chunk reads.  Layer 1 alone: its last row + 2.  The fused launch: the chunk ends on a multiple of 8 LOCAL rows, which
