@@ -281,8 +281,10 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
     bool feeder_done = false;
     std::atomic<int> drain_rc{W2XC_OK};
     std::string drain_err;
+    // (started with the first chunk it is handed, not at the call's start: creating a thread costs tens of microseconds the first upload would wait behind)
     std::thread drainer;
-    if (!out_pinned) {
+    auto start_drainer = [&] {
+        if (out_pinned || drainer.joinable()) return;
         drainer = std::thread([&] {
             hipSetDevice(dev);
             for (;;) {
@@ -380,7 +382,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
                 qcv.notify_all();
             }
         });
-    }
+    };
     auto finish_drainer = [&] {
         if (drainer.joinable()) {
             { std::lock_guard<std::mutex> ql(qmu); feeder_done = true; }
@@ -446,6 +448,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
             HIP_TRY(hipMemcpyAsync(p.pin_out + (size_t)slot * p.out_slot_bytes, p.d_out + (size_t)(a - ra) * W, (size_t)(b2 - a) * out_row,
                                    hipMemcpyDeviceToHost, p.s_d2h));
             HIP_TRY(hipEventRecord(p.ev_out_slot[slot], p.s_d2h));
+            start_drainer();
             {
                 std::lock_guard<std::mutex> ql(qmu);
                 pending.push_back({a, b2, slot});
@@ -503,6 +506,7 @@ int host_rows_on_device(w2xc_model *m, int dev, const float *in_, size_t in_stri
         Chunk ch{y0, y1, -1};
         ch.trows = trows; ch.groups = groups; ch.first = first;
         ch.flags = p.pin_flags[par]; ch.epoch = p.flags_epoch[par]; ch.src = p.pin_band[par];
+        start_drainer();
         {
             std::lock_guard<std::mutex> ql(qmu);
             pending.push_back(ch);
