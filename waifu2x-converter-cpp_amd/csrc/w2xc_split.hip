@@ -568,8 +568,11 @@ __global__ void __launch_bounds__(WM *WN * 64, WM *WN / 4) conv3x3_split(W2xcCon
             const unsigned lane_ob = (unsigned)(OT == 0 ? li * COUT + 4 * kk : li * GRP + 4 * kk) * OES;   // this lane's byte offset inside the tile
             auto oofs = [&](int mb, int nb, int i) -> long long {   // element offset of channels (nb0+nb)*32 + 8i + 4kk .. +3
                 if (OT == 0) return obase + (long long)mb * d.out_rs + nb * 32 + 8 * i;
-                const int c = (nb0 + nb) * 32 + 8 * i + 4 * kk;
-                return obase + (long long)mb * d.out_rs + (long long)(c / GRP) * d.out_gs + c % GRP;
+                // (GRP = 16: the channel group (nb0 + nb) * 2 + i / 2 is wave-uniform -- written as c / GRP with the lane's kk inside c, its product with out_gs
+                //  became a 64-bit per-lane value per (nb, i), hoisted out of the tile loop and spilled: 34 registers in the 128 -> 128 bf16 kernel, round 6)
+                static_assert(GRP == 16, "channel groups of 16");
+                const int cg = (nb0 + nb) * 2 + (i >> 1), cl = 8 * (i & 1) + 4 * kk;
+                return obase + (long long)mb * d.out_rs + (long long)cg * d.out_gs + cl;
             };
             if constexpr (OT == 9) {
                 // ---- the last layer (cin = COUT -> 1 plane, 3x3) inside this epilogue, "taps as rows":
