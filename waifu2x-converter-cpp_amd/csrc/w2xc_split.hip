@@ -807,12 +807,21 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kk = lane >> 5, li = lane & 31;
 
-    // ---- 1. input patch ----
-    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
-        const int py = idx / PW, px = idx - py * PW;
-        const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;
-        const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;
-        lds[idx] = d.in[(long long)gy * d.in_rs + (long long)gx * d.in_ps];
+    // ---- 1. input patch (every pass's load in flight at once: as a loop it was load / s_waitcnt vmcnt(0) / write per pass) ----
+    {
+        constexpr int PP = (PH * PW + 255) / 256;
+        float pv[PP];
+#pragma unroll
+        for (int t = 0; t < PP; t++) {
+            const int idx = min((int)threadIdx.x + 256 * t, PH * PW - 1);
+            const int py = idx / PW, px = idx - py * PW;
+            const int gy = clampi(oy0 + py + d.off_y, 0, d.in_h - 1) >> d.in_shift;
+            const int gx = clampi(ox0 + px + d.off_x, 0, d.in_w - 1) >> d.in_shift;
+            pv[t] = d.in[(long long)gy * d.in_rs + (long long)gx * d.in_ps];
+        }
+#pragma unroll
+        for (int t = 0; t < PP; t++)
+            if ((int)threadIdx.x + 256 * t < PH * PW) lds[threadIdx.x + 256 * t] = pv[t];
     }
     float w1[S], b1[16];
 #pragma unroll
@@ -943,19 +952,26 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
     }
 
     // ---- epilogue of layer 2: bias + LeakyReLU, term planes (blocked) or fp32 NHWC ----
+    // (a plane block's four bias quads are fetched once, in front of its stores: fetched per store, every store stood behind s_waitcnt vmcnt(0) for its bias --
+    //  and with it for the store before; the channel group c / 16 = 2 nb + i / 2 is wave-uniform and written so: round 6, found in the ISA)
     const int x = ox0 + li;
 #pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-        const int y = oy0 + wave * MB + mb;
-        const bool in = (y < d.out_h) && (x < d.out_w);
+    for (int nb = 0; nb < NBT; nb++) {
+        f32x4 bqs[4];
 #pragma unroll
-        for (int nb = 0; nb < NBT; nb++)
+        for (int i = 0; i < 4; i++) {
+            bqs[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (!BINIT) bqs[i] = *reinterpret_cast<const f32x4 *>(d.bias + nb * 32 + 8 * i + 4 * kk);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+            const int y = oy0 + wave * MB + mb;
+            const bool in = (y < d.out_h) && (x < d.out_w);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int c = nb * 32 + 8 * i + 4 * kk;
                 float v[4];
-                f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (!BINIT) bq = *reinterpret_cast<const f32x4 *>(d.bias + c);
+                const f32x4 bq = bqs[i];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float sacc = FMT ? acc2[mb][nb][4 * i + e] * d.acc_scale : acc2[mb][nb][4 * i + e];
@@ -963,9 +979,10 @@ __global__ void __launch_bounds__(256) conv3x3_first2_split(W2xcConvDesc d, int 
                     else { const float sb = sacc + bq[e]; v[e] = fmaxf(sb, 0.1f * sb); }
                 }
                 const long long o = OT == 0 ? (long long)y * d.out_rs + (long long)x * COUT + c
-                                            : (long long)(c / 16) * d.out_gs + (long long)y * d.out_rs + (long long)x * 16 + c % 16;
+                                            : (long long)(nb * 2 + (i >> 1)) * d.out_gs + (long long)y * d.out_rs + (long long)x * 16 + (8 * (i & 1) + 4 * kk);
                 if (in) store_terms<OT, FMT>(d.out, o, d.out_ts, v[0], v[1], v[2], v[3]);
             }
+        }
     }
 }
 
