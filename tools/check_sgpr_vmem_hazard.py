@@ -5,7 +5,7 @@ operands is checked against the instructions in front of it (v_readlane / v_read
 import re, subprocess, sys, tempfile, os
 obj = sys.argv[1]
 T = tempfile.mkdtemp()
-subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--dump-section", ".hip_fatbin=%s/fat.bin" % T, obj])
+subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--dump-section", ".hip_fatbin=%s/fat.bin" % T, obj, "%s/copy.o" % T])   # (explicit output: the input stays untouched)
 subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=%s/fat.bin" % T,
                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=%s/k.co" % T])
 txt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "%s/k.co" % T]).decode()
